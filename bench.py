@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json metric):
+SA build chars/s (N = 1e9) + batched queries/s (Q = 1e6) on one MI355X, % of HBM roofline.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--n CHARS] [--q QUERIES]
+
+A "step" = one device build of the suffix array of the N-char synthetic text D1 (uniform27,
+SURVEY.md 8d; text resident in HBM before the timed region) + one batch of Q 16-byte queries
+(50 % text windows, 50 % random; patterns resident in HBM).  N > 1 GPUs (launched by
+torch.distributed.run, one rank per GPU): construction does not shard ("replicas only", every
+rank builds its own replica); the query batch is weak-scaled (Q per GPU) and the results are
+all-gathered over RCCL; the one-time RCCL broadcast of (text, SA) is timed separately.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # MI355X HBM3E peak, B/s (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(text, q_buf, q_off, sample_n, sample_q):
+    """Reference libsais64_omp (oracle/_ref, compiled from the reference's own sources) on a
+    bounded prefix of the same text, all host cores; falls back to the oracle port."""
+    from oracle.oracle import Oracle, Ref
+    t = np.ascontiguousarray(text[:sample_n])
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_DYNAMIC", "false")
+    out = {}
+    orc = Oracle()
+    if Ref.available():
+        ref = Ref()
+        sa64 = np.zeros(t.size, dtype=np.int64)  # first-touched
+        t0 = time.perf_counter()
+        rc = ref.libsais64_into(t, sa64, 0)
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        out.update(kind="reference", value=t.size / dt, unit="chars/s", cores=cores,
+                   sample=f"libsais64_omp(threads=0 -> {cores}) on the first {t.size:,} chars of the same text, 1 run: {dt:.2f} s")
+        sa = sa64.astype(np.uint32)
+    else:
+        t0 = time.perf_counter()
+        sa = orc.sais(t).astype(np.uint32)
+        dt = time.perf_counter() - t0
+        out.update(kind="port", value=t.size / dt, unit="chars/s", cores=1,
+                   sample=f"oracle SA-IS port on the first {t.size:,} chars, 1 run: {dt:.2f} s")
+    # query baseline: oracle restatement of get_substring_positions, OpenMP over the batch
+    nq = min(sample_q, q_off.size - 1)
+    t0 = time.perf_counter()
+    orc.query_batch(t, sa, 0xFFFFFFFF, (q_buf[:int(q_off[nq])], q_off[:nq + 1]), threads=0)
+    dq = time.perf_counter() - t0
+    out["queries_per_s"] = nq / dq
+    out["query_sample"] = f"{nq:,} of the same 16-byte patterns over the sample SA, {orc.threads_used} threads: {dq:.2f} s"
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1_000_000_000)
+    ap.add_argument("--q", type=int, default=1_000_000)
+    ap.add_argument("--pattern-len", type=int, default=16)
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from suffixarray_amd import _capi, synth
+    from suffixarray_amd.distributed import broadcast_index
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    N, Q, m = args.n, args.q, args.pattern_len
+    text = synth.d1_uniform27(N)                     # same text on every rank
+    q_buf, q_off = synth.query_batch(text, Q, m, seed=rank)  # each rank's own slice of the global batch
+
+    idx = _capi.DeviceIndex(N, local_rank)
+    idx.build(text)                                  # uploads the text into the index's HBM buffer
+    text_dev = idx.text_dev
+    pat_t = torch.from_numpy(np.concatenate([q_buf, np.zeros(64, np.uint8)])).to(dev)
+    off_t = torch.from_numpy(q_off.view(np.int64)).to(dev)
+    out_t = torch.zeros(2 * Q, dtype=torch.int32, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        idx.build_device(text_dev, N, 0)
+        idx.query_batch_device(pat_t.data_ptr(), off_t.data_ptr(), Q, out_t.data_ptr())
+        idx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    build_ms, radix_ms, radix_launches, radix_bytes, query_ms = 0.0, 0.0, 0, 0, 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        st = idx.build_stats()
+        build_ms += st["total_ms"]
+        radix_ms += st["radix_ms"]
+        radix_launches += st["radix_passes"]
+        radix_bytes += st["radix_bytes"]
+        query_ms += idx.query_stats()["kernel_ms"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt, build_ms, query_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt, build_ms_max, query_ms_max = tmax.tolist()
+    else:
+        build_ms_max, query_ms_max = build_ms, query_ms
+    last = idx.build_stats()
+
+    # one-time replication cost (north_star): RCCL broadcast of text + SA from rank 0
+    bcast_ms = None
+    if world > 1:
+        sa_t = torch.empty(N, dtype=torch.int32, device=dev)
+        tx_t = torch.empty(N, dtype=torch.uint8, device=dev)
+        barrier()
+        b0 = time.perf_counter()
+        broadcast_index(tx_t, sa_t, src=0)
+        barrier()
+        bcast_ms = (time.perf_counter() - b0) * 1e3
+        del sa_t, tx_t
+
+    # correctness gate inside the bench: the SA of the last step is a suffix array (spot checks)
+    gate = None
+    if rank == 0:
+        res = out_t.cpu().numpy().view(np.uint32).reshape(-1, 2)
+        hits = ((res[:, 1].astype(np.int64) - res[:, 0].astype(np.int64) + 1) & 0xFFFFFFFF) > 0
+        hits &= res[:, 0] != 0xFFFFFFFF
+        probe = idx.sa_range(0, min(N, 1 << 16)).astype(np.int64)
+        ok = True
+        for a, b in zip(probe[:-1:97], probe[1::97]):
+            ok &= bytes(text[a:a + 64]) <= bytes(text[b:b + 64])
+        gate = {"sorted_probe_ok": bool(ok), "query_hit_rate": float(hits.mean())}
+
+    if rank == 0:
+        steps = args.steps
+        chars_per_s = world * N * steps / (build_ms_max / 1e3)          # replicas: every rank builds N chars
+        queries_per_s = world * Q * steps / (query_ms_max / 1e3)
+        pass_ms = radix_ms / max(radix_launches, 1)
+        bytes_per_launch = radix_bytes / max(radix_launches, 1)
+        achieved = radix_bytes / (radix_ms / 1e3) if radix_ms > 0 else 0.0
+        bq = 2 * int(np.ceil(np.log2(max(N, 2)))) * (4 + m)              # reference bytes per query
+        q_achieved = Q * steps * bq / (query_ms / 1e3) if query_ms > 0 else 0.0
+        line = {
+            "metric": "sa_build_chars_per_s",
+            "value": chars_per_s,
+            "unit": "chars/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 text / u64 keys / u32 suffix indices",
+            "data": "synthetic",
+            "config": {"workload": f"D1 uniform27 text N={N:,} (32-bit device build, libsais64-compatible 64-bit output by widening kernel) + {Q:,} batched {m}-byte queries per GPU",
+                       "n_chars": N, "queries_per_gpu": Q, "pattern_len": m,
+                       "parallelism": "replicas (build) + sharded query batch" if world > 1 else "single GPU"},
+            "build_ms": build_ms_max / steps,
+            "queries_per_s": queries_per_s,
+            "query_ms": query_ms_max / steps,
+            "broadcast_ms": bcast_ms,
+            "build_stats": {k: last[k] for k in ("sigma", "bits_per_symbol", "initial_chars", "rounds", "chunk_rounds",
+                                                 "doubling_rounds", "final_depth", "radix_passes", "active_total")},
+            "roofline": {"bound": "hbm", "kernel": "radix_onesweep_kernel", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "launches": radix_launches, "avg_launch_ms": pass_ms, "bytes_per_launch": bytes_per_launch},
+            "roofline_query": {"bound": "hbm", "kernel": "query_kernel", "achieved": q_achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                               "unit": "GB/s", "frac": q_achieved / HBM_PEAK, "bytes_per_query_model": bq},
+            "gate": gate,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(text, q_buf, q_off, min(args.cpu_sample, N), min(Q, 1_000_000))
+        print(json.dumps(line))
+    idx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

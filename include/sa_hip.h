@@ -1,0 +1,184 @@
+/*
+ * sa_hip.h -- C ABI of libsa_hip.so: MI355X (gfx950) suffix-array construction and batched
+ * substring query.  Plain C types only; no C++, HIP or torch types cross this boundary
+ * (device pointers and the stream travel as void*).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * reference repository jdm365/SuffixArray @ 2024_10_08).  INTEGRATION.md shows the
+ * reference-side binding (Cython `cdef extern`, Makefile link line).
+ *
+ * Error convention: libsais' (libsais.h:82-94) -- 0 ok, -1 invalid arguments, -2 out of
+ * (host or device) memory; additionally -3 HIP runtime / no usable device, -4 internal
+ * device-side failure (bounded spin expired).  Nothing here calls exit() or prints.
+ * sa_hip_last_error() returns a thread-local message for the last non-zero return.
+ *
+ * Threading: every function may be called without the GIL.  A handle owns one HIP stream;
+ * calls on the same handle are serialised by an internal mutex; different handles are
+ * independent.  The libsais-/engine-compatible wrappers create a private handle per call.
+ */
+#ifndef SA_HIP_H
+#define SA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SA_HIP_OK            0
+#define SA_HIP_EINVAL       (-1)
+#define SA_HIP_ENOMEM       (-2)
+#define SA_HIP_EHIP         (-3)
+#define SA_HIP_EINTERNAL    (-4)
+
+/* ---- ABI structs (layout identical to the reference's) --------------------------------- */
+
+/* engine.h:219-222 */
+typedef struct sa_hip_pair_u32 {
+    uint32_t first;
+    uint32_t second;
+} sa_hip_pair_u32;
+
+/* engine.h:123-130 SuffixArray_struct; sizeof == 40.  is_quoted_bitflag is opaque here. */
+typedef struct sa_hip_SuffixArray_struct {
+    uint32_t* suffix_array;
+    void*     is_quoted_bitflag;
+    uint64_t  global_byte_start_idx;
+    uint64_t  global_byte_end_idx;
+    uint32_t  max_suffix_length;
+    uint32_t  n;
+} sa_hip_SuffixArray_struct;
+
+/* ---- (1) construction, libsais-call-compatible (host pointers in, host SA out) ---------- */
+
+/* replaces libsais (libsais.h:84, libsais.c:6618).  SA[0..n) <- suffix array of T[0..n);
+ * SA[n..n+fs) untouched; freq (if non-NULL) <- 256-bin byte histogram. */
+int32_t sa_hip_libsais(const uint8_t* T, int32_t* SA, int32_t n, int32_t fs, int32_t* freq);
+/* replaces libsais_omp (libsais.h:121, libsais.c:6791).  threads is validated (>= 0) and
+ * otherwise ignored: the device pipeline has no host thread pool. */
+int32_t sa_hip_libsais_omp(const uint8_t* T, int32_t* SA, int32_t n, int32_t fs, int32_t* freq, int32_t threads);
+/* replaces libsais64 (libsais64.h:61, libsais64.c:6657).  n <= UINT32_MAX - 1: 32-bit device
+ * build + widening kernel (the reference does the same on the CPU, libsais64.c:6670-6682). */
+int64_t sa_hip_libsais64(const uint8_t* T, int64_t* SA, int64_t n, int64_t fs, int64_t* freq);
+/* replaces libsais64_omp (libsais64.h:86, libsais64.c:6783). */
+int64_t sa_hip_libsais64_omp(const uint8_t* T, int64_t* SA, int64_t n, int64_t fs, int64_t* freq, int64_t threads);
+
+/* ---- (2) truncated construction, engine.c-call-compatible ------------------------------- */
+
+/* replaces construct_truncated_suffix_array (engine.h:213, engine.c:837-866).
+ * Fills the caller-allocated sa->suffix_array[0..sa->n) with the suffixes of text[0..sa->n)
+ * ordered by their first min(sa->max_suffix_length, n) bytes (unsigned, a suffix that ends
+ * sorts first), ties in text order.  Returns 0 or a negative SA_HIP_* code (the reference
+ * returns void and exit()s on failure). */
+int sa_hip_construct_truncated_suffix_array(const char* text, sa_hip_SuffixArray_struct* sa);
+
+/* ---- (3) query -------------------------------------------------------------------------- */
+
+/* replaces get_substring_positions (engine.h:229-233, engine.c:869-918): one query, host
+ * text (n bytes; a trailing NUL is not required) and host SA.  Uploads text and SA, runs the
+ * batched kernel with Q = 1.  For repeated queries use the handle API below. */
+sa_hip_pair_u32 sa_hip_get_substring_positions(const char* str, const sa_hip_SuffixArray_struct* sa,
+                                               const char* substring);
+
+/* ---- (4) handle API: text + SA resident in HBM ------------------------------------------ */
+
+typedef struct sa_hip_index sa_hip_index;
+
+/* Number of HIP devices visible to this process, or a negative SA_HIP_* code. */
+int sa_hip_device_count(void);
+
+/* Create an empty index bound to `device` with capacity for texts of up to n_max bytes
+ * (device workspace is allocated here, not in the build call). n_max <= UINT32_MAX - 1. */
+int sa_hip_index_create(sa_hip_index** out, uint64_t n_max, int device);
+void sa_hip_index_destroy(sa_hip_index* idx);
+
+/* Build from a host text (H2D copy + device build).  max_suffix_length == 0: full suffix
+ * array (libsais order); > 0: truncated order as in (2). */
+int sa_hip_index_build(sa_hip_index* idx, const uint8_t* T_host, uint64_t n, uint32_t max_suffix_length);
+/* Same, text already in device memory of idx's device (copied device-to-device into the index). */
+int sa_hip_index_build_device(sa_hip_index* idx, const void* T_dev, uint64_t n, uint32_t max_suffix_length);
+/* Adopt an existing suffix array (host pointers): uploads T and SA and prepares the query
+ * structures; SA must be sorted by the first max_suffix_length bytes (0 = fully sorted). */
+int sa_hip_index_load(sa_hip_index* idx, const uint8_t* T_host, const uint32_t* SA_host, uint64_t n,
+                      uint32_t max_suffix_length);
+/* Same with device pointers (multi-GPU replicas: T and SA arrive by RCCL broadcast). */
+int sa_hip_index_load_device(sa_hip_index* idx, const void* T_dev, const void* SA_dev, uint64_t n,
+                             uint32_t max_suffix_length);
+
+uint64_t sa_hip_index_n(const sa_hip_index* idx);
+uint32_t sa_hip_index_max_suffix_length(const sa_hip_index* idx);
+/* Device pointers owned by the index: text (n bytes + zero padding) and SA (uint32[n]). */
+const void* sa_hip_index_text_dev(const sa_hip_index* idx);
+const void* sa_hip_index_sa_dev(const sa_hip_index* idx);
+/* The index's HIP stream (hipStream_t as void*), for event timing by the caller. */
+void* sa_hip_index_stream(const sa_hip_index* idx);
+
+/* Copy the suffix array to the host: uint32[n]; int32[n] (libsais layout); int64[n] (libsais64
+ * layout, widened on the device). */
+int sa_hip_index_get_sa_u32(sa_hip_index* idx, uint32_t* out_host);
+int sa_hip_index_get_sa_i64(sa_hip_index* idx, int64_t* out_host);
+/* 256-bin byte histogram of the indexed text (libsais `freq`). */
+int sa_hip_index_get_freq(sa_hip_index* idx, uint64_t* freq256);
+
+/* Batched get_substring_positions (engine.c:869-918 per element).  Pattern i is
+ * patterns[offsets[i] .. offsets[i+1]); compare length c = min(len, max_suffix_length) when
+ * the index is truncated, len otherwise.  out[i] = {first,last} inclusive SA range;
+ * {UINT32_MAX,UINT32_MAX} when every suffix is smaller; miss -> first = lower bound,
+ * last = first - 1 (mod 2^32).  An empty pattern matches every suffix: {0, n-1}.
+ * Host pointers; H2D/D2H copies are issued on the index's stream. */
+int sa_hip_query_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_t* offsets, uint64_t Q,
+                       sa_hip_pair_u32* out);
+/* Same with every buffer in device memory (no copies; asynchronous on the index's stream
+ * until sa_hip_index_sync). */
+int sa_hip_query_batch_device(sa_hip_index* idx, const void* patterns_dev, const void* offsets_dev,
+                              uint64_t Q, void* out_dev);
+/* Copy up to `cap` suffix positions SA[first .. first+count) to the host (hit materialisation). */
+int sa_hip_index_get_sa_range(sa_hip_index* idx, uint64_t first, uint64_t count, uint32_t* out_host);
+
+int sa_hip_index_sync(sa_hip_index* idx);
+
+/* ---- instrumentation ---------------------------------------------------------------------- */
+
+/* Per-build statistics of the last build on this handle (roofline accounting). */
+typedef struct sa_hip_build_stats {
+    uint64_t n;
+    uint32_t sigma;              /* distinct byte values                                   */
+    uint32_t bits_per_symbol;    /* b: code width after alphabet compaction                */
+    uint32_t initial_chars;      /* K0: characters packed into the initial 64-bit key      */
+    uint32_t rounds;             /* refinement rounds after the initial sort               */
+    uint32_t chunk_rounds;
+    uint32_t doubling_rounds;
+    uint32_t final_depth;        /* h when the active set became empty                     */
+    uint32_t radix_passes;       /* onesweep launches over all sorts                       */
+    uint64_t radix_records;      /* sum over passes of records moved                       */
+    uint64_t radix_bytes;        /* algorithmic bytes of those passes: 2*M*(8+4) each      */
+    uint64_t active_total;       /* sum over rounds of active-set sizes                    */
+    double   radix_ms;           /* HIP-event time of all onesweep launches                */
+    double   total_ms;           /* HIP-event time of the whole device build               */
+} sa_hip_build_stats;
+int sa_hip_index_build_stats(const sa_hip_index* idx, sa_hip_build_stats* out);
+
+/* Per-query-batch statistics of the last batch on this handle. */
+typedef struct sa_hip_query_stats {
+    uint64_t q;
+    double   kernel_ms;          /* HIP-event time of the search kernel(s)                 */
+} sa_hip_query_stats;
+int sa_hip_index_query_stats(const sa_hip_index* idx, sa_hip_query_stats* out);
+
+/* Stable LSD radix sort of n (u64 key, u32 value) records by key bits [begin_bit, end_bit) on
+ * `device` (host pointers, sorted in place).  The device sort underneath every build, exported
+ * so that it can be tested and profiled on its own.  values == NULL: values are the record
+ * positions 0..n-1 and are not returned. */
+int sa_hip_sort_pairs(uint64_t* keys, uint32_t* values, uint64_t n, int begin_bit, int end_bit, int device);
+
+/* Synthetic text D1 `uniform27` of SURVEY.md 8(d): xorshift64 stream, 26 letters + '\n'. */
+void sa_hip_synth_uniform27(uint8_t* out, uint64_t n, uint64_t seed);
+
+const char* sa_hip_last_error(void);
+const char* sa_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SA_HIP_H */

@@ -1,0 +1,332 @@
+"""ctypes binding of the C ABI in include/sa_hip.h (libsa_hip.so, built in-tree by build.py).
+
+This is the only way Python reaches the device code: no torch types cross the boundary, device
+pointers travel as integers.  There is NO CPU fallback -- if the library is missing or no HIP
+device is usable, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsa_hip.so")
+
+PAIR_DTYPE = np.dtype([("first", "<u4"), ("second", "<u4")])
+UINT32_MAX = 0xFFFFFFFF
+
+# every symbol include/sa_hip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "sa_hip_libsais", "sa_hip_libsais_omp", "sa_hip_libsais64", "sa_hip_libsais64_omp",
+    "sa_hip_construct_truncated_suffix_array", "sa_hip_get_substring_positions",
+    "sa_hip_device_count", "sa_hip_index_create", "sa_hip_index_destroy", "sa_hip_index_build",
+    "sa_hip_index_build_device", "sa_hip_index_load", "sa_hip_index_load_device", "sa_hip_index_n",
+    "sa_hip_index_max_suffix_length", "sa_hip_index_text_dev", "sa_hip_index_sa_dev",
+    "sa_hip_index_stream", "sa_hip_index_get_sa_u32", "sa_hip_index_get_sa_i64",
+    "sa_hip_index_get_freq", "sa_hip_query_batch", "sa_hip_query_batch_device",
+    "sa_hip_index_get_sa_range", "sa_hip_index_sync", "sa_hip_index_build_stats",
+    "sa_hip_index_query_stats", "sa_hip_sort_pairs", "sa_hip_synth_uniform27", "sa_hip_last_error", "sa_hip_version",
+]
+
+
+class PairU32(C.Structure):
+    _fields_ = [("first", C.c_uint32), ("second", C.c_uint32)]
+
+
+class SuffixArrayStruct(C.Structure):
+    """engine.h:123-130 layout (sa_hip_SuffixArray_struct)."""
+    _fields_ = [("suffix_array", C.c_void_p), ("is_quoted_bitflag", C.c_void_p),
+                ("global_byte_start_idx", C.c_uint64), ("global_byte_end_idx", C.c_uint64),
+                ("max_suffix_length", C.c_uint32), ("n", C.c_uint32)]
+
+
+class BuildStats(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("sigma", C.c_uint32), ("bits_per_symbol", C.c_uint32),
+                ("initial_chars", C.c_uint32), ("rounds", C.c_uint32), ("chunk_rounds", C.c_uint32),
+                ("doubling_rounds", C.c_uint32), ("final_depth", C.c_uint32), ("radix_passes", C.c_uint32),
+                ("radix_records", C.c_uint64), ("radix_bytes", C.c_uint64), ("active_total", C.c_uint64),
+                ("radix_ms", C.c_double), ("total_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class QueryStats(C.Structure):
+    _fields_ = [("q", C.c_uint64), ("kernel_ms", C.c_double)]
+
+
+class SaHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsa_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libsa_hip.so (raises if it has not been built: there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: run `python -m suffixarray_amd.build` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32, i64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_int64
+    L.sa_hip_libsais.restype = i32
+    L.sa_hip_libsais.argtypes = [vp, vp, i32, i32, vp]
+    L.sa_hip_libsais_omp.restype = i32
+    L.sa_hip_libsais_omp.argtypes = [vp, vp, i32, i32, vp, i32]
+    L.sa_hip_libsais64.restype = i64
+    L.sa_hip_libsais64.argtypes = [vp, vp, i64, i64, vp]
+    L.sa_hip_libsais64_omp.restype = i64
+    L.sa_hip_libsais64_omp.argtypes = [vp, vp, i64, i64, vp, i64]
+    L.sa_hip_construct_truncated_suffix_array.restype = C.c_int
+    L.sa_hip_construct_truncated_suffix_array.argtypes = [vp, C.POINTER(SuffixArrayStruct)]
+    L.sa_hip_get_substring_positions.restype = PairU32
+    L.sa_hip_get_substring_positions.argtypes = [vp, C.POINTER(SuffixArrayStruct), C.c_char_p]
+    L.sa_hip_device_count.restype = C.c_int
+    L.sa_hip_device_count.argtypes = []
+    L.sa_hip_index_create.restype = C.c_int
+    L.sa_hip_index_create.argtypes = [C.POINTER(vp), u64, C.c_int]
+    L.sa_hip_index_destroy.restype = None
+    L.sa_hip_index_destroy.argtypes = [vp]
+    L.sa_hip_index_build.restype = C.c_int
+    L.sa_hip_index_build.argtypes = [vp, vp, u64, u32]
+    L.sa_hip_index_build_device.restype = C.c_int
+    L.sa_hip_index_build_device.argtypes = [vp, vp, u64, u32]
+    L.sa_hip_index_load.restype = C.c_int
+    L.sa_hip_index_load.argtypes = [vp, vp, vp, u64, u32]
+    L.sa_hip_index_load_device.restype = C.c_int
+    L.sa_hip_index_load_device.argtypes = [vp, vp, vp, u64, u32]
+    L.sa_hip_index_n.restype = u64
+    L.sa_hip_index_n.argtypes = [vp]
+    L.sa_hip_index_max_suffix_length.restype = u32
+    L.sa_hip_index_max_suffix_length.argtypes = [vp]
+    L.sa_hip_index_text_dev.restype = vp
+    L.sa_hip_index_text_dev.argtypes = [vp]
+    L.sa_hip_index_sa_dev.restype = vp
+    L.sa_hip_index_sa_dev.argtypes = [vp]
+    L.sa_hip_index_stream.restype = vp
+    L.sa_hip_index_stream.argtypes = [vp]
+    L.sa_hip_index_get_sa_u32.restype = C.c_int
+    L.sa_hip_index_get_sa_u32.argtypes = [vp, vp]
+    L.sa_hip_index_get_sa_i64.restype = C.c_int
+    L.sa_hip_index_get_sa_i64.argtypes = [vp, vp]
+    L.sa_hip_index_get_freq.restype = C.c_int
+    L.sa_hip_index_get_freq.argtypes = [vp, vp]
+    L.sa_hip_query_batch.restype = C.c_int
+    L.sa_hip_query_batch.argtypes = [vp, vp, vp, u64, vp]
+    L.sa_hip_query_batch_device.restype = C.c_int
+    L.sa_hip_query_batch_device.argtypes = [vp, vp, vp, u64, vp]
+    L.sa_hip_index_get_sa_range.restype = C.c_int
+    L.sa_hip_index_get_sa_range.argtypes = [vp, u64, u64, vp]
+    L.sa_hip_index_sync.restype = C.c_int
+    L.sa_hip_index_sync.argtypes = [vp]
+    L.sa_hip_index_build_stats.restype = C.c_int
+    L.sa_hip_index_build_stats.argtypes = [vp, C.POINTER(BuildStats)]
+    L.sa_hip_index_query_stats.restype = C.c_int
+    L.sa_hip_index_query_stats.argtypes = [vp, C.POINTER(QueryStats)]
+    L.sa_hip_sort_pairs.restype = C.c_int
+    L.sa_hip_sort_pairs.argtypes = [vp, vp, u64, C.c_int, C.c_int, C.c_int]
+    L.sa_hip_synth_uniform27.restype = None
+    L.sa_hip_synth_uniform27.argtypes = [vp, u64, u64]
+    L.sa_hip_last_error.restype = C.c_char_p
+    L.sa_hip_last_error.argtypes = []
+    L.sa_hip_version.restype = C.c_char_p
+    L.sa_hip_version.argtypes = []
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise SaHipError(rc, lib().sa_hip_last_error().decode("utf-8", "replace"))
+
+
+def as_u8(a):
+    if isinstance(a, (bytes, bytearray, memoryview)):
+        return np.frombuffer(a, dtype=np.uint8)
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def pack_patterns(patterns):
+    """list[bytes] -> (packed uint8 array, uint64 offsets[Q+1])"""
+    off = np.zeros(len(patterns) + 1, dtype=np.uint64)
+    if len(patterns):
+        off[1:] = np.cumsum([len(p) for p in patterns], dtype=np.uint64)
+    buf = np.frombuffer(b"".join(patterns), dtype=np.uint8) if len(patterns) else np.zeros(0, np.uint8)
+    return buf, off
+
+
+class DeviceIndex:
+    """Handle API: text + suffix array resident in HBM (sa_hip_index)."""
+
+    def __init__(self, n_max, device=0):
+        self._h = C.c_void_p()
+        self._lib = lib()
+        check(self._lib.sa_hip_index_create(C.byref(self._h), int(n_max), int(device)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.sa_hip_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- construction -------------------------------------------------------------------------
+    def build(self, text, max_suffix_length=0):
+        t = as_u8(text)
+        check(self._lib.sa_hip_index_build(self._h, t.ctypes.data if t.size else None, t.size, max_suffix_length))
+        return self
+
+    def build_device(self, text_dev_ptr, n, max_suffix_length=0):
+        check(self._lib.sa_hip_index_build_device(self._h, text_dev_ptr, n, max_suffix_length))
+        return self
+
+    def load(self, text, sa, max_suffix_length=0):
+        t = as_u8(text)
+        s = np.ascontiguousarray(sa, dtype=np.uint32)
+        assert s.size == t.size
+        check(self._lib.sa_hip_index_load(self._h, t.ctypes.data if t.size else None,
+                                          s.ctypes.data if s.size else None, t.size, max_suffix_length))
+        return self
+
+    def load_device(self, text_dev_ptr, sa_dev_ptr, n, max_suffix_length=0):
+        check(self._lib.sa_hip_index_load_device(self._h, text_dev_ptr, sa_dev_ptr, n, max_suffix_length))
+        return self
+
+    # -- accessors ----------------------------------------------------------------------------
+    @property
+    def n(self):
+        return int(self._lib.sa_hip_index_n(self._h))
+
+    @property
+    def max_suffix_length(self):
+        return int(self._lib.sa_hip_index_max_suffix_length(self._h))
+
+    @property
+    def text_dev(self):
+        return self._lib.sa_hip_index_text_dev(self._h)
+
+    @property
+    def sa_dev(self):
+        return self._lib.sa_hip_index_sa_dev(self._h)
+
+    def sa_u32(self):
+        out = np.empty(max(self.n, 1), dtype=np.uint32)
+        check(self._lib.sa_hip_index_get_sa_u32(self._h, out.ctypes.data))
+        return out[:self.n]
+
+    def sa_i64(self):
+        out = np.empty(max(self.n, 1), dtype=np.int64)
+        check(self._lib.sa_hip_index_get_sa_i64(self._h, out.ctypes.data))
+        return out[:self.n]
+
+    def sa_range(self, first, count):
+        out = np.empty(max(count, 1), dtype=np.uint32)
+        check(self._lib.sa_hip_index_get_sa_range(self._h, first, count, out.ctypes.data))
+        return out[:count]
+
+    def freq(self):
+        out = np.zeros(256, dtype=np.uint64)
+        check(self._lib.sa_hip_index_get_freq(self._h, out.ctypes.data))
+        return out
+
+    def sync(self):
+        check(self._lib.sa_hip_index_sync(self._h))
+
+    def build_stats(self):
+        st = BuildStats()
+        check(self._lib.sa_hip_index_build_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def query_stats(self):
+        st = QueryStats()
+        check(self._lib.sa_hip_index_query_stats(self._h, C.byref(st)))
+        return {"q": st.q, "kernel_ms": st.kernel_ms}
+
+    # -- query ----------------------------------------------------------------------------------
+    def query_batch(self, patterns):
+        """patterns: list[bytes] or (packed uint8, uint64 offsets).  -> structured array (first, second)."""
+        buf, off = patterns if isinstance(patterns, tuple) else pack_patterns(patterns)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        q = off.size - 1
+        out = np.zeros(max(q, 1), dtype=PAIR_DTYPE)
+        if q:
+            check(self._lib.sa_hip_query_batch(self._h, buf.ctypes.data if buf.size else None, off.ctypes.data, q,
+                                               out.ctypes.data))
+        return out[:q]
+
+    def query_batch_device(self, patterns_dev_ptr, offsets_dev_ptr, q, out_dev_ptr):
+        check(self._lib.sa_hip_query_batch_device(self._h, patterns_dev_ptr, offsets_dev_ptr, q, out_dev_ptr))
+
+
+# -- libsais- / engine-compatible one-shot wrappers ----------------------------------------------
+
+def libsais(text, want_freq=False):
+    t = as_u8(text)
+    sa = np.empty(max(t.size, 1), dtype=np.int32)
+    freq = np.zeros(256, dtype=np.int32)
+    rc = lib().sa_hip_libsais(t.ctypes.data, sa.ctypes.data, t.size, 0, freq.ctypes.data if want_freq else None)
+    check(rc)
+    return (sa[:t.size], freq) if want_freq else sa[:t.size]
+
+
+def libsais64(text, want_freq=False):
+    t = as_u8(text)
+    sa = np.empty(max(t.size, 1), dtype=np.int64)
+    freq = np.zeros(256, dtype=np.int64)
+    rc = lib().sa_hip_libsais64(t.ctypes.data, sa.ctypes.data, t.size, 0, freq.ctypes.data if want_freq else None)
+    check(int(rc))
+    return (sa[:t.size], freq) if want_freq else sa[:t.size]
+
+
+def construct_truncated_suffix_array(text, max_suffix_length):
+    t = as_u8(text)
+    sa = np.zeros(max(t.size, 1), dtype=np.uint32)
+    st = SuffixArrayStruct()
+    st.suffix_array = sa.ctypes.data
+    st.max_suffix_length = max_suffix_length
+    st.n = t.size
+    st.global_byte_end_idx = t.size
+    check(lib().sa_hip_construct_truncated_suffix_array(t.ctypes.data, C.byref(st)))
+    return sa[:t.size]
+
+
+def get_substring_positions(text, sa, max_suffix_length, substring):
+    t = as_u8(text)
+    s = np.ascontiguousarray(sa, dtype=np.uint32)
+    st = SuffixArrayStruct()
+    st.suffix_array = s.ctypes.data
+    st.max_suffix_length = max_suffix_length
+    st.n = t.size
+    r = lib().sa_hip_get_substring_positions(t.ctypes.data, C.byref(st), bytes(substring))
+    return (r.first, r.second)
+
+
+def sort_pairs(keys, values=None, begin_bit=0, end_bit=64, device=0):
+    """In-place stable device sort of (u64 key, u32 value) records; returns (keys, values)."""
+    k = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+    v = None if values is None else np.ascontiguousarray(values, dtype=np.uint32).copy()
+    check(lib().sa_hip_sort_pairs(k.ctypes.data if k.size else None, None if v is None else v.ctypes.data,
+                                  k.size, begin_bit, end_bit, device))
+    return k, v
+
+
+def synth_uniform27(n, seed=88172645463325252):
+    out = np.empty(n, dtype=np.uint8)
+    lib().sa_hip_synth_uniform27(out.ctypes.data, n, seed)
+    return out

@@ -1,0 +1,38 @@
+"""In-tree build of libsa_hip.so for gfx950 (hipcc cross-compiles without a GPU).
+
+    python -m suffixarray_amd.build [--force]
+"""
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB = os.path.join(_HERE, "libsa_hip.so")
+SOURCES = ["sa_capi.hip"]
+HEADERS = ["common.hpp", "radix_sort.hpp", "sa_build.hpp", "sa_query.hpp", os.path.join("..", "..", "include", "sa_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_lib(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    cmd = [HIPCC] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv, verbose=True)
+    print(LIB)

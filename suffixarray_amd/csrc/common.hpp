@@ -1,0 +1,62 @@
+// common.hpp -- shared host/device helpers for libsa_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/sa_hip.h"
+
+namespace sa {
+
+using u8 = uint8_t;
+using u16 = uint16_t;
+using u32 = uint32_t;
+using u64 = uint64_t;
+
+constexpr int WAVE = 64;  // gfx950 wavefront width
+
+// thread-local last error text (sa_hip_last_error)
+inline std::string& last_error() {
+    static thread_local std::string s;
+    return s;
+}
+inline int fail(int code, const char* what, const char* detail = nullptr) {
+    std::string& e = last_error();
+    e = what;
+    if (detail) { e += ": "; e += detail; }
+    return code;
+}
+
+#define SA_HIP_CHECK(expr)                                                                 \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            char _b[256];                                                                  \
+            snprintf(_b, sizeof _b, "%s:%d %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+            return ::sa::fail(_e == hipErrorOutOfMemory ? SA_HIP_ENOMEM : SA_HIP_EHIP, #expr, _b); \
+        }                                                                                  \
+    } while (0)
+
+__host__ __device__ inline u32 div_up(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+
+// smallest b with 2^b >= count
+inline int bits_for(u64 count) {
+    int b = 0;
+    while (b < 64 && (1ull << b) < count) ++b;
+    return b;
+}
+
+__device__ __forceinline__ u64 lanemask_lt() {
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+// Device error word shared by every kernel that can spin (decoupled look-back).
+// 0 = ok; anything else = a bounded spin expired, results are invalid.
+struct DeviceStatus {
+    u32 error;
+    u32 pad[3];
+};
+
+}  // namespace sa

@@ -1,0 +1,638 @@
+// sa_build.hpp -- device suffix-array construction for gfx950: alphabet compaction, packed
+// initial keys, one-sweep radix sort, then refinement rounds over the ACTIVE set only
+// (suffixes whose group is not yet a singleton): "chunk" rounds append the next characters of
+// the text to the key, "doubling" rounds (Larsson-Sadakane with discarding) append the rank of
+// suffix i+h.  tests/pipeline_model.py is the executable specification of the host logic.
+//
+// Replaces, by function only, libsais / libsais64 (libsais.c:6618, libsais64.c:6657: T -> SA)
+// and construct_truncated_suffix_array (engine.c:837-866).  Order: unsigned bytes, a suffix
+// that is a proper prefix of another sorts first (libsais.c:703-707); truncated mode orders by
+// the first L bytes with ties in text order.
+//
+// HBM layout (n = text bytes, M = active records of a round):
+//   text     u8 [n + TEXT_PAD]   zero padded, read coalesced (keygen) or by random 8..64 B windows
+//   keys0/1  u64[n]              ping-pong sort keys (initial sort)
+//   vals0/1  u32[n]              ping-pong suffix indices; the result buffer IS the suffix array
+//   flags    u8 [n]              bit0 = group head at this SA slot
+//   isa      u32[n]              rank of every suffix (allocated on the first doubling round)
+//   round pool (37 B x M0)       apos/aidx/gid lists, round keys + indices ping-pong, local flags
+#pragma once
+#include <vector>
+
+#include "common.hpp"
+#include "radix_sort.hpp"
+
+namespace sa {
+
+constexpr int TEXT_PAD = 256;        // readable zero bytes after the text
+constexpr int BLD_BLOCK = 256;
+constexpr int BLD_ITEMS = 16;
+constexpr int BLD_TILE = BLD_BLOCK * BLD_ITEMS;  // 4096 elements per workgroup
+constexpr u32 NONE32 = 0xFFFFFFFFu;
+
+struct CodeMap {
+    u16 code[256];  // 0 = byte absent (never looked up for a present position); 1..sigma
+};
+
+// ---- byte histogram (libsais `freq`, libsais.c:1363-1371) -------------------------------------
+__global__ __launch_bounds__(256) void byte_hist_kernel(const u8* __restrict__ text, u64 n, u64* __restrict__ hist) {
+    __shared__ u32 s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 nvec = n / 16;
+    const uint4* v = reinterpret_cast<const uint4*>(text);
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const uint4 x = v[i];
+        const u32 w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            atomicAdd(&s_h[w[k] & 255u], 1u);
+            atomicAdd(&s_h[(w[k] >> 8) & 255u], 1u);
+            atomicAdd(&s_h[(w[k] >> 16) & 255u], 1u);
+            atomicAdd(&s_h[w[k] >> 24], 1u);
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (u64 i = nvec * 16 + threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_h[text[i]], 1u);
+    }
+    __syncthreads();
+    const u32 c = s_h[threadIdx.x];
+    if (c) atomicAdd((unsigned long long*)&hist[threadIdx.x], (unsigned long long)c);
+}
+
+// ---- initial keys: key[i] = codes of T[i..i+k0) packed MSB-first, b bits each ----------------------
+// One workgroup stages BLD_TILE + k0 text bytes as codes in LDS (16-byte global loads), every
+// thread then assembles the keys of 16 positions (stride 256 -> 8-byte coalesced stores).
+__global__ __launch_bounds__(BLD_BLOCK) void keygen_kernel(const u8* __restrict__ text, u64 n, CodeMap map, int b,
+                                                           int k0, u64* __restrict__ keys) {
+    __shared__ u16 s_map[256];
+    __shared__ u16 s_codes[BLD_TILE + 64 + 16];
+    s_map[threadIdx.x] = map.code[threadIdx.x];
+    const u64 ntiles = (n + BLD_TILE - 1) / BLD_TILE;
+    for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const u64 base = tile * BLD_TILE;
+        __syncthreads();
+        {   // body: 16 bytes per thread (text is padded by >= 16 readable bytes past n)
+            uint4 x = make_uint4(0, 0, 0, 0);
+            if (base + (u64)threadIdx.x * 16 < n) x = *reinterpret_cast<const uint4*>(text + base + (u64)threadIdx.x * 16);
+            const u32 w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const u64 p = base + (u64)threadIdx.x * 16 + k;
+                const u32 byte = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
+                s_codes[threadIdx.x * 16 + k] = (p < n) ? s_map[byte] : (u16)0;
+            }
+        }
+        if (threadIdx.x < 64 + 16) {  // halo
+            const u64 p = base + BLD_TILE + threadIdx.x;
+            s_codes[BLD_TILE + threadIdx.x] = (p < n) ? s_map[text[p]] : (u16)0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < BLD_ITEMS; ++it) {
+            const u32 l = it * BLD_BLOCK + threadIdx.x;
+            const u64 p = base + l;
+            if (p < n) {
+                u64 key = 0;
+                int sh = 64;
+                for (int j = 0; j < k0; ++j) {
+                    sh -= b;
+                    key |= (u64)s_codes[l + j] << sh;
+                }
+                keys[p] = key;
+            }
+        }
+    }
+}
+
+// ---- head / active flags + per-tile counts -------------------------------------------------------------
+// lf[j]: bit0 = head (key differs from predecessor), bit1 = active (group of j has > 1 member).
+// Optional write-back of a refinement round: SA[apos[j]] = sidx[j]; gflags[apos[j]] |= head.
+// counts[tile] = {#active, #active heads} of the tile.
+__global__ __launch_bounds__(BLD_BLOCK) void flags_kernel(const u64* __restrict__ keys, u32 n, u8* __restrict__ lf,
+                                                          uint2* __restrict__ counts, const u32* __restrict__ apos,
+                                                          const u32* __restrict__ sidx, u32* __restrict__ sa_out,
+                                                          u8* __restrict__ gflags) {
+    __shared__ u32 s_a[BLD_BLOCK / WAVE], s_h[BLD_BLOCK / WAVE];
+    const u64 base = (u64)blockIdx.x * BLD_TILE;
+    u32 ca = 0, ch = 0;
+#pragma unroll 4
+    for (int it = 0; it < BLD_ITEMS; ++it) {
+        const u64 j = base + (u64)it * BLD_BLOCK + threadIdx.x;
+        if (j < n) {
+            const u64 k = keys[j];
+            const bool head = (j == 0) || (keys[j - 1] != k);
+            const bool next_head = (j + 1 == n) || (keys[j + 1] != k);
+            const bool act = !(head && next_head);
+            lf[j] = (u8)((head ? 1 : 0) | (act ? 2 : 0));
+            ca += act;
+            ch += (act && head);
+            if (apos) {
+                const u32 slot = apos[j];
+                sa_out[slot] = sidx[j];
+                if (head) gflags[slot] = 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ca += __shfl_down(ca, o);
+        ch += __shfl_down(ch, o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_a[wave] = ca; s_h[wave] = ch; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 ta = 0, th = 0;
+        for (int w = 0; w < BLD_BLOCK / WAVE; ++w) { ta += s_a[w]; th += s_h[w]; }
+        counts[blockIdx.x] = make_uint2(ta, th);
+    }
+}
+
+// exclusive scan of the per-tile {active, heads} pairs, single workgroup; totals[0..1] = sums
+__global__ __launch_bounds__(1024) void scan_counts_kernel(uint2* __restrict__ counts, u32 ntiles, u32* __restrict__ totals) {
+    __shared__ u32 s_a[1024], s_h[1024];
+    const u32 per = (ntiles + 1023) / 1024;
+    const u32 lo = threadIdx.x * per;
+    const u32 hi = (lo + per < ntiles) ? lo + per : ntiles;
+    u32 a = 0, h = 0;
+    for (u32 i = lo; i < hi; ++i) { a += counts[i].x; h += counts[i].y; }
+    s_a[threadIdx.x] = a; s_h[threadIdx.x] = h;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        u32 ta = 0, th = 0;
+        if ((int)threadIdx.x >= o) { ta = s_a[threadIdx.x - o]; th = s_h[threadIdx.x - o]; }
+        __syncthreads();
+        s_a[threadIdx.x] += ta; s_h[threadIdx.x] += th;
+        __syncthreads();
+    }
+    u32 ea = s_a[threadIdx.x] - a, eh = s_h[threadIdx.x] - h;
+    for (u32 i = lo; i < hi; ++i) {
+        const uint2 c = counts[i];
+        counts[i] = make_uint2(ea, eh);
+        ea += c.x; eh += c.y;
+    }
+    if (threadIdx.x == 1023) { totals[0] = s_a[1023]; totals[1] = s_h[1023]; }
+}
+
+// ---- compaction of the active elements ---------------------------------------------------------------
+// dst_pos[m] = SA slot, dst_idx[m] = suffix index, dst_gid[m] = dense id of its group among the
+// active groups.  src_pos == nullptr: the domain is the whole SA (slot = j).
+__global__ __launch_bounds__(BLD_BLOCK) void compact_kernel(const u8* __restrict__ lf, u32 n,
+                                                            const uint2* __restrict__ offsets,
+                                                            const u32* __restrict__ src_pos,
+                                                            const u32* __restrict__ src_idx, u32* __restrict__ dst_pos,
+                                                            u32* __restrict__ dst_idx, u32* __restrict__ dst_gid) {
+    constexpr int WAVES = BLD_BLOCK / WAVE;
+    __shared__ u32 s_a[WAVES], s_h[WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 lt = lanemask_lt();
+    const uint2 off = offsets[blockIdx.x];
+    u32 a_off = off.x, h_off = off.y;
+    const u64 base = (u64)blockIdx.x * BLD_TILE;
+    for (int it = 0; it < BLD_ITEMS; ++it) {
+        const u64 j = base + (u64)it * BLD_BLOCK + threadIdx.x;
+        const u32 f = (j < n) ? lf[j] : 0u;
+        const bool act = (f & 2u) != 0;
+        const bool ah = act && (f & 1u);
+        const u64 ba = __ballot(act), bh = __ballot(ah);
+        if (lane == 0) { s_a[wave] = (u32)__popcll(ba); s_h[wave] = (u32)__popcll(bh); }
+        __syncthreads();
+        u32 wa = 0, wh = 0, ta = 0, th = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            if (w < wave) { wa += s_a[w]; wh += s_h[w]; }
+            ta += s_a[w]; th += s_h[w];
+        }
+        if (act) {
+            const u32 m = a_off + wa + (u32)__popcll(ba & lt);
+            const u32 g = h_off + wh + (u32)__popcll(bh & lt) + (ah ? 1u : 0u) - 1u;
+            dst_pos[m] = src_pos ? src_pos[j] : (u32)j;
+            dst_idx[m] = src_idx[j];
+            dst_gid[m] = g;
+        }
+        a_off += ta; h_off += th;
+        __syncthreads();
+    }
+}
+
+// ---- round keys ------------------------------------------------------------------------------------------
+// chunk round: key = gid << (64-gb) | next kc characters of the text after depth h (b bits each)
+__global__ __launch_bounds__(256) void chunk_keys_kernel(const u8* __restrict__ text, u64 n, CodeMap map, int b,
+                                                         const u32* __restrict__ aidx, const u32* __restrict__ gid,
+                                                         u32 m_count, u32 h, int kc, int gb, u64* __restrict__ keys) {
+    __shared__ u16 s_map[256];
+    s_map[threadIdx.x] = map.code[threadIdx.x];
+    __syncthreads();
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 m = (u64)blockIdx.x * blockDim.x + threadIdx.x; m < m_count; m += stride) {
+        const u64 start = (u64)aidx[m] + h;
+        u64 key = gb ? ((u64)gid[m] << (64 - gb)) : 0ull;
+        int sh = 64 - gb;
+        for (int j = 0; j < kc; ++j) {
+            const u64 p = start + j;
+            sh -= b;
+            const u64 c = (p < n) ? (u64)s_map[text[p]] : 0ull;
+            key |= c << sh;
+        }
+        keys[m] = key;
+    }
+}
+
+// doubling round: key = gid << rb | (rank of suffix idx+h) + 1, 0 when idx+h == n
+__global__ __launch_bounds__(256) void doubling_keys_kernel(const u32* __restrict__ isa, u64 n,
+                                                            const u32* __restrict__ aidx, const u32* __restrict__ gid,
+                                                            u32 m_count, u64 h, int rb, u64* __restrict__ keys) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 m = (u64)blockIdx.x * blockDim.x + threadIdx.x; m < m_count; m += stride) {
+        const u64 p = (u64)aidx[m] + h;
+        const u64 k2 = (p < n) ? (u64)isa[p] + 1ull : 0ull;
+        keys[m] = ((u64)gid[m] << rb) | k2;
+    }
+}
+
+// ---- group starts (ranks) ----------------------------------------------------------------------------------
+// last head value per tile (value = slot of the head: posmap[j] or j), NONE32 if the tile has none
+__global__ __launch_bounds__(BLD_BLOCK) void tile_last_head_kernel(const u8* __restrict__ lf, u32 n,
+                                                                   const u32* __restrict__ posmap,
+                                                                   u32* __restrict__ tile_last) {
+    __shared__ u32 s_w[BLD_BLOCK / WAVE];
+    const u64 base = (u64)blockIdx.x * BLD_TILE;
+    int64_t best = -1;  // largest j with a head
+    for (int it = 0; it < BLD_ITEMS; ++it) {
+        const u64 j = base + (u64)it * BLD_BLOCK + threadIdx.x;
+        if (j < n && (lf[j] & 1u)) best = (int64_t)j;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int64_t t = __shfl_down(best, o);
+        best = t > best ? t : best;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int64_t s_b[BLD_BLOCK / WAVE];
+    if (lane == 0) s_b[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t bb = -1;
+        for (int w = 0; w < BLD_BLOCK / WAVE; ++w) bb = s_b[w] > bb ? s_b[w] : bb;
+        tile_last[blockIdx.x] = (bb < 0) ? NONE32 : (posmap ? posmap[bb] : (u32)bb);
+    }
+    (void)s_w;
+}
+
+// exclusive "last defined value" scan over tiles, single workgroup:
+// carry[t] = value of the last tile < t that has a head (NONE32 if none)
+__global__ __launch_bounds__(1024) void scan_last_head_kernel(const u32* __restrict__ tile_last, u32 ntiles,
+                                                              u32* __restrict__ carry) {
+    __shared__ u32 s_v[1024];
+    const u32 per = (ntiles + 1023) / 1024;
+    const u32 lo = threadIdx.x * per;
+    const u32 hi = (lo + per < ntiles) ? lo + per : ntiles;
+    u32 v = NONE32;
+    for (u32 i = lo; i < hi; ++i) { const u32 t = tile_last[i]; if (t != NONE32) v = t; }
+    s_v[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        u32 t = NONE32;
+        if ((int)threadIdx.x >= o) t = s_v[threadIdx.x - o];
+        __syncthreads();
+        if (s_v[threadIdx.x] == NONE32) s_v[threadIdx.x] = t;
+        __syncthreads();
+    }
+    u32 c = (threadIdx.x == 0) ? NONE32 : s_v[threadIdx.x - 1];
+    for (u32 i = lo; i < hi; ++i) {
+        carry[i] = c;
+        const u32 t = tile_last[i];
+        if (t != NONE32) c = t;
+    }
+}
+
+// isa[idx[j]] = slot of the head of j's group
+__global__ __launch_bounds__(BLD_BLOCK) void scatter_ranks_kernel(const u8* __restrict__ lf, u32 n,
+                                                                  const u32* __restrict__ posmap,
+                                                                  const u32* __restrict__ idx,
+                                                                  const u32* __restrict__ carry,
+                                                                  u32* __restrict__ isa) {
+    constexpr int WAVES = BLD_BLOCK / WAVE;
+    __shared__ u32 s_last[WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 le = lanemask_lt() | (1ull << lane);
+    u32 run = carry[blockIdx.x];
+    const u64 base = (u64)blockIdx.x * BLD_TILE;
+    for (int it = 0; it < BLD_ITEMS; ++it) {
+        const u64 j = base + (u64)it * BLD_BLOCK + threadIdx.x;
+        const bool in = j < n;
+        const bool head = in && (lf[j] & 1u);
+        const u32 myval = in ? (posmap ? posmap[j] : (u32)j) : 0u;
+        const u64 bh = __ballot(head);
+        const u64 mine = bh & le;
+        const int src = mine ? (63 - __clzll((long long)mine)) : 0;
+        const u32 from_wave = __shfl(myval, src);
+        const int lastlane = bh ? (63 - __clzll((long long)bh)) : 0;
+        const u32 wave_last = __shfl(myval, lastlane);
+        if (lane == 0) s_last[wave] = bh ? wave_last : NONE32;
+        __syncthreads();
+        u32 prev = run;  // last head before this wave in this iteration, else the running carry
+        u32 newrun = run;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const u32 t = s_last[w];
+            if (t != NONE32) {
+                if (w < wave) prev = t;
+                newrun = t;
+            }
+        }
+        if (in) isa[idx[j]] = mine ? from_wave : prev;
+        run = newrun;
+        __syncthreads();
+    }
+}
+
+__global__ void widen_kernel(const u32* __restrict__ sa, u64 n, int64_t* __restrict__ out) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (int64_t)sa[i];
+}
+
+__global__ void iota_kernel(u32* __restrict__ out, u64 n) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (u32)i;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        SA_HIP_CHECK(hipMalloc(&p, bytes));
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline u32 stream_grid(u64 work_items, u32 per_block) {
+    u64 g = (work_items + per_block - 1) / per_block;
+    if (g > 256u * 8u) g = 256u * 8u;
+    if (g == 0) g = 1;
+    return (u32)g;
+}
+
+struct Builder {
+    hipStream_t stream = nullptr;
+    u64 n_max = 0;
+    // persistent buffers
+    DevBuf text, keys0, keys1, vals0, vals1, flags, counts, small, isa;
+    // round pool
+    DevBuf apos0, apos1, aidx, gid, rkeys0, rkeys1, ridx0, ridx1, lf, tile_last, carry;
+    RadixWorkspace radix;
+    u32* sa = nullptr;        // points into vals0/vals1 after a build (or into sa_own after load)
+    DevBuf sa_own;
+    u64 n = 0;
+    u32 max_suffix_length = 0;
+    u64 freq[256];
+    sa_hip_build_stats stats;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    int chunk_rounds_before_doubling = 2;
+
+    int init(u64 nmax, hipStream_t s) {
+        stream = s;
+        n_max = nmax;
+        const u64 cap = nmax ? nmax : 1;
+        int rc;
+        if ((rc = text.ensure(cap + TEXT_PAD + 16))) return rc;
+        if ((rc = small.ensure(4096))) return rc;
+        if ((rc = radix.init(cap))) return rc;
+        SA_HIP_CHECK(hipEventCreate(&ev_begin));
+        SA_HIP_CHECK(hipEventCreate(&ev_end));
+        memset(&stats, 0, sizeof stats);
+        memset(freq, 0, sizeof freq);
+        return 0;
+    }
+    int ensure_build_buffers() {
+        const u64 cap = n_max ? n_max : 1;
+        int rc;
+        if ((rc = keys0.ensure(cap * 8))) return rc;
+        if ((rc = keys1.ensure(cap * 8))) return rc;
+        if ((rc = vals0.ensure(cap * 4))) return rc;
+        if ((rc = vals1.ensure(cap * 4))) return rc;
+        if ((rc = flags.ensure(cap))) return rc;
+        if ((rc = counts.ensure((size_t)div_up(cap, BLD_TILE) * sizeof(uint2) + 64))) return rc;
+        return 0;
+    }
+    void destroy() {
+        DevBuf* all[] = {&text, &keys0, &keys1, &vals0, &vals1, &flags, &counts, &small, &isa, &apos0, &apos1, &aidx,
+                         &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own};
+        for (DevBuf* b : all) b->release();
+        radix.destroy();
+        if (ev_begin) (void)hipEventDestroy(ev_begin);
+        if (ev_end) (void)hipEventDestroy(ev_end);
+        ev_begin = ev_end = nullptr;
+    }
+
+    // text must already be in text.p[0..n); pads it and computes freq + code map
+    int prepare_text(u64 n_, CodeMap& map, u32& sigma, int& b) {
+        n = n_;
+        SA_HIP_CHECK(hipMemsetAsync(text.as<u8>() + n, 0, TEXT_PAD + 16, stream));
+        u64* dh = small.as<u64>();
+        SA_HIP_CHECK(hipMemsetAsync(dh, 0, 256 * sizeof(u64), stream));
+        if (n) hipLaunchKernelGGL(byte_hist_kernel, dim3(stream_grid(n, 256 * 64)), dim3(256), 0, stream, text.as<u8>(), n, dh);
+        SA_HIP_CHECK(hipMemcpyAsync(freq, dh, sizeof freq, hipMemcpyDeviceToHost, stream));
+        SA_HIP_CHECK(hipStreamSynchronize(stream));
+        sigma = 0;
+        memset(&map, 0, sizeof map);
+        for (int c = 0; c < 256; ++c)
+            if (freq[c]) map.code[c] = (u16)(++sigma);
+        b = bits_for((u64)sigma + 1);
+        if (b == 0) b = 1;
+        return 0;
+    }
+
+    int read_totals(u32* totals_host) {
+        SA_HIP_CHECK(hipMemcpyAsync(totals_host, small.as<u8>() + 2048, 2 * sizeof(u32), hipMemcpyDeviceToHost, stream));
+        SA_HIP_CHECK(hipStreamSynchronize(stream));
+        return 0;
+    }
+    u32* totals_dev() { return reinterpret_cast<u32*>(small.as<u8>() + 2048); }
+
+    int check_device_status() {
+        DeviceStatus st;
+        SA_HIP_CHECK(hipMemcpyAsync(&st, radix.dstat, sizeof st, hipMemcpyDeviceToHost, stream));
+        SA_HIP_CHECK(hipStreamSynchronize(stream));
+        if (st.error != 0) {
+            (void)hipMemsetAsync(radix.dstat, 0, sizeof(DeviceStatus), stream);
+            return fail(SA_HIP_EINTERNAL, "device look-back spin limit expired");
+        }
+        return 0;
+    }
+
+    // head/active flags over `cnt` sorted keys (+ optional round write-back), scanned counts.
+    int flags_and_counts(const u64* keys, u32 cnt, u8* lf_out, const u32* apos, const u32* sidx, u32* totals_host) {
+        const u32 tiles = div_up(cnt, BLD_TILE);
+        hipLaunchKernelGGL(flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, keys, cnt, lf_out, counts.as<uint2>(),
+                           apos, sidx, sa, flags.as<u8>());
+        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, counts.as<uint2>(), tiles, totals_dev());
+        return read_totals(totals_host);
+    }
+
+    // isa[idx[j]] = head slot of j's group over a domain of cnt elements
+    int scatter_ranks(const u8* lf_in, u32 cnt, const u32* posmap, const u32* idx) {
+        const u32 tiles = div_up(cnt, BLD_TILE);
+        int rc;
+        if ((rc = tile_last.ensure((size_t)tiles * 4 + 64))) return rc;
+        if ((rc = carry.ensure((size_t)tiles * 4 + 64))) return rc;
+        hipLaunchKernelGGL(tile_last_head_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, lf_in, cnt, posmap, tile_last.as<u32>());
+        hipLaunchKernelGGL(scan_last_head_kernel, dim3(1), dim3(1024), 0, stream, tile_last.as<u32>(), tiles, carry.as<u32>());
+        hipLaunchKernelGGL(scatter_ranks_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, lf_in, cnt, posmap, idx,
+                           carry.as<u32>(), isa.as<u32>());
+        return 0;
+    }
+
+    // The device build.  Text already resident in text.p[0..n_).
+    int build(u64 n_, u32 L) {
+        int rc;
+        memset(&stats, 0, sizeof stats);
+        radix.reset_stats();
+        max_suffix_length = L;
+        stats.n = n_;
+        if (n_ > n_max) return fail(SA_HIP_EINVAL, "text longer than the index capacity");
+        if ((rc = ensure_build_buffers())) return rc;
+        SA_HIP_CHECK(hipEventRecord(ev_begin, stream));
+        CodeMap map;
+        u32 sigma = 0;
+        int b = 1;
+        if ((rc = prepare_text(n_, map, sigma, b))) return rc;
+        stats.sigma = sigma;
+        stats.bits_per_symbol = (u32)b;
+        sa = vals0.as<u32>();
+        if (n == 0) return finish_stats();
+        if (n == 1) {
+            SA_HIP_CHECK(hipMemsetAsync(sa, 0, 4, stream));
+            SA_HIP_CHECK(hipMemsetAsync(flags.p, 1, 1, stream));
+            return finish_stats();
+        }
+        int k0 = 64 / b;
+        if (L && (u32)k0 > L) k0 = (int)L;
+        stats.initial_chars = (u32)k0;
+        const u32 n32 = (u32)n;
+
+        // initial keys + sort #0
+        hipLaunchKernelGGL(keygen_kernel, dim3(stream_grid(n, BLD_TILE)), dim3(BLD_BLOCK), 0, stream, text.as<u8>(), n, map, b,
+                           k0, keys0.as<u64>());
+        u64* kres; u32* vres;
+        if ((rc = radix_sort_pairs(radix, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(), n32,
+                                   64 - b * k0, 64, true, &kres, &vres))) return rc;
+        sa = vres;
+
+        // head flags, active counts
+        u32 tot[2];
+        if ((rc = flags_and_counts(kres, n32, flags.as<u8>(), nullptr, nullptr, tot))) return rc;
+        if ((rc = check_device_status())) return rc;
+        u32 M = tot[0], G = tot[1];
+        u64 h = (u64)k0;
+        bool have_isa = false;
+        int chunk_done = 0;
+
+        if (M && (L == 0 || h < L)) {
+            const size_t m0 = M;
+            if ((rc = apos0.ensure(m0 * 4))) return rc;
+            if ((rc = apos1.ensure(m0 * 4))) return rc;
+            if ((rc = aidx.ensure(m0 * 4))) return rc;
+            if ((rc = gid.ensure(m0 * 4))) return rc;
+            if ((rc = rkeys0.ensure(m0 * 8))) return rc;
+            if ((rc = rkeys1.ensure(m0 * 8))) return rc;
+            if ((rc = ridx0.ensure(m0 * 4))) return rc;
+            if ((rc = ridx1.ensure(m0 * 4))) return rc;
+            if ((rc = lf.ensure(m0))) return rc;
+            // first compaction: domain = whole SA
+            hipLaunchKernelGGL(compact_kernel, dim3(div_up(n32, BLD_TILE)), dim3(BLD_BLOCK), 0, stream, flags.as<u8>(), n32,
+                               counts.as<uint2>(), (const u32*)nullptr, (const u32*)sa, apos0.as<u32>(), aidx.as<u32>(),
+                               gid.as<u32>());
+        }
+        u32* apos_cur = apos0.as<u32>();
+        u32* apos_nxt = apos1.as<u32>();
+        const int rb = bits_for(n + 1);
+
+        while (M && (L == 0 || h < L)) {
+            const int gb = bits_for(G);
+            bool use_chunk = (L != 0) || (chunk_done < chunk_rounds_before_doubling);
+            int kc = 0;
+            if (use_chunk) {
+                kc = (64 - gb) / b;
+                if (L && (u64)kc > L - h) kc = (int)(L - h);
+                if (kc <= 0) use_chunk = false;
+            }
+            int begin_bit;
+            u64 h_next;
+            if (use_chunk) {
+                hipLaunchKernelGGL(chunk_keys_kernel, dim3(stream_grid(M, 256)), dim3(256), 0, stream, text.as<u8>(), n, map, b,
+                                   aidx.as<u32>(), gid.as<u32>(), M, (u32)h, kc, gb, rkeys0.as<u64>());
+                begin_bit = 64 - gb - b * kc;
+                h_next = h + kc;
+                ++chunk_done;
+                ++stats.chunk_rounds;
+            } else {
+                if (L != 0) return fail(SA_HIP_EINTERNAL, "truncated build cannot make progress");
+                if (gb + rb > 64) return fail(SA_HIP_EINTERNAL, "composite key exceeds 64 bits");
+                if (!have_isa) {
+                    if ((rc = isa.ensure((size_t)n * 4))) return rc;
+                    if ((rc = scatter_ranks(flags.as<u8>(), n32, nullptr, sa))) return rc;
+                    have_isa = true;
+                }
+                hipLaunchKernelGGL(doubling_keys_kernel, dim3(stream_grid(M, 256)), dim3(256), 0, stream, isa.as<u32>(), n,
+                                   aidx.as<u32>(), gid.as<u32>(), M, h, rb, rkeys0.as<u64>());
+                begin_bit = 0;
+                h_next = 2 * h;
+                ++stats.doubling_rounds;
+            }
+            // sort the active records; aidx is the value array
+            SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
+            const int end_bit = use_chunk ? 64 : (gb + rb);
+            if ((rc = radix_sort_pairs(radix, stream, rkeys0.as<u64>(), ridx0.as<u32>(), rkeys1.as<u64>(), ridx1.as<u32>(), M,
+                                       begin_bit, end_bit, false, &kres, &vres))) return rc;
+            // write back, new heads, counts
+            if ((rc = flags_and_counts(kres, M, lf.as<u8>(), apos_cur, vres, tot))) return rc;
+            if ((rc = check_device_status())) return rc;
+            if (have_isa) {
+                if ((rc = scatter_ranks(lf.as<u8>(), M, apos_cur, vres))) return rc;
+            }
+            stats.active_total += M;
+            ++stats.rounds;
+            h = h_next;
+            const u32 M_next = tot[0];
+            if (M_next && (L == 0 || h < L)) {
+                hipLaunchKernelGGL(compact_kernel, dim3(div_up(M, BLD_TILE)), dim3(BLD_BLOCK), 0, stream, lf.as<u8>(), M,
+                                   counts.as<uint2>(), (const u32*)apos_cur, (const u32*)vres, apos_nxt, aidx.as<u32>(),
+                                   gid.as<u32>());
+                u32* t = apos_cur; apos_cur = apos_nxt; apos_nxt = t;
+            }
+            M = M_next;
+            G = tot[1];
+            if (stats.rounds > 200) return fail(SA_HIP_EINTERNAL, "refinement did not converge");
+        }
+        stats.final_depth = (u32)(h > 0xFFFFFFFFull ? 0xFFFFFFFFull : h);
+        return finish_stats();
+    }
+
+    int finish_stats() {
+        SA_HIP_CHECK(hipEventRecord(ev_end, stream));
+        SA_HIP_CHECK(hipEventSynchronize(ev_end));
+        float ms = 0.f;
+        SA_HIP_CHECK(hipEventElapsedTime(&ms, ev_begin, ev_end));
+        int rc = radix.timer.flush();
+        if (rc) return rc;
+        stats.total_ms = ms;
+        stats.radix_ms = radix.timer.total_ms;
+        stats.radix_passes = (u32)radix.passes;
+        stats.radix_records = radix.pass_records;
+        stats.radix_bytes = radix.pass_records * 2ull * 12ull;
+        return 0;
+    }
+};
+
+}  // namespace sa

@@ -1,0 +1,412 @@
+// sa_capi.hip -- the C ABI of libsa_hip.so (include/sa_hip.h).  Single translation unit for
+// gfx950: hipcc --offload-arch=gfx950 -shared -fPIC.  No CPU fallback: every entry point needs
+// a HIP device and fails with SA_HIP_EHIP when there is none.
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "common.hpp"
+#include "radix_sort.hpp"
+#include "sa_build.hpp"
+#include "sa_query.hpp"
+
+using namespace sa;
+
+struct sa_hip_index {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    Builder b;
+    bool has_index = false;
+    // query staging (host-pointer API)
+    DevBuf q_pat, q_off, q_out;
+    DevBuf widen;
+    hipEvent_t q_begin = nullptr, q_end = nullptr;
+    sa_hip_query_stats qstats{};
+};
+
+namespace {
+
+int set_device(int device) {
+    SA_HIP_CHECK(hipSetDevice(device));
+    return 0;
+}
+
+int launch_query(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q, sa_hip_pair_u32* out_dev) {
+    QueryArgs a;
+    a.text = idx->b.text.as<u8>();
+    a.sa = idx->b.sa;
+    a.n = idx->b.n;
+    a.max_suffix_length = idx->b.max_suffix_length;
+    a.patterns = pat_dev;
+    a.offsets = off_dev;
+    a.q = Q;
+    a.out = out_dev;
+    SA_HIP_CHECK(hipEventRecord(idx->q_begin, idx->stream));
+    if (Q) {
+        u64 g = (Q + 255) / 256;
+        if (g > 256u * 16u) g = 256u * 16u;
+        hipLaunchKernelGGL(query_kernel, dim3((u32)g), dim3(256), 0, idx->stream, a);
+    }
+    SA_HIP_CHECK(hipEventRecord(idx->q_end, idx->stream));
+    SA_HIP_CHECK(hipGetLastError());
+    idx->qstats.q = Q;
+    idx->qstats.kernel_ms = -1.0;  // resolved lazily by sa_hip_index_query_stats
+    return 0;
+}
+
+// one-shot helper for the libsais-/engine-compatible wrappers
+struct TempIndex {
+    sa_hip_index* idx = nullptr;
+    ~TempIndex() { if (idx) sa_hip_index_destroy(idx); }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* sa_hip_last_error(void) { return last_error().c_str(); }
+const char* sa_hip_version(void) { return "suffixarray_amd 0.1 (gfx950)"; }
+
+int sa_hip_device_count(void) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) return fail(SA_HIP_EHIP, "hipGetDeviceCount", hipGetErrorString(e));
+    return c;
+}
+
+int sa_hip_index_create(sa_hip_index** out, uint64_t n_max, int device) {
+    if (!out) return fail(SA_HIP_EINVAL, "sa_hip_index_create: out == NULL");
+    *out = nullptr;
+    if (n_max > 0xFFFFFFFEull) return fail(SA_HIP_EINVAL, "sa_hip_index_create: n_max exceeds 2^32 - 2");
+    int cnt = sa_hip_device_count();
+    if (cnt < 0) return cnt;
+    if (device < 0 || device >= cnt) return fail(SA_HIP_EHIP, "sa_hip_index_create: no such HIP device");
+    int rc = set_device(device);
+    if (rc) return rc;
+    sa_hip_index* idx = new (std::nothrow) sa_hip_index();
+    if (!idx) return fail(SA_HIP_ENOMEM, "sa_hip_index_create: host allocation");
+    idx->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete idx; return fail(SA_HIP_EHIP, "hipStreamCreate", hipGetErrorString(e)); }
+    rc = idx->b.init(n_max, idx->stream);
+    if (!rc) {
+        if (hipEventCreate(&idx->q_begin) != hipSuccess || hipEventCreate(&idx->q_end) != hipSuccess)
+            rc = fail(SA_HIP_EHIP, "hipEventCreate");
+    }
+    if (rc) { sa_hip_index_destroy(idx); return rc; }
+    *out = idx;
+    return 0;
+}
+
+void sa_hip_index_destroy(sa_hip_index* idx) {
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+    idx->b.destroy();
+    idx->q_pat.release(); idx->q_off.release(); idx->q_out.release(); idx->widen.release();
+    if (idx->q_begin) (void)hipEventDestroy(idx->q_begin);
+    if (idx->q_end) (void)hipEventDestroy(idx->q_end);
+    if (idx->stream) (void)hipStreamDestroy(idx->stream);
+    delete idx;
+}
+
+int sa_hip_index_build(sa_hip_index* idx, const uint8_t* T_host, uint64_t n, uint32_t max_suffix_length) {
+    if (!idx || (!T_host && n)) return fail(SA_HIP_EINVAL, "sa_hip_index_build: NULL argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    if (n > idx->b.n_max) return fail(SA_HIP_EINVAL, "sa_hip_index_build: n exceeds the index capacity");
+    if (n) SA_HIP_CHECK(hipMemcpyAsync(idx->b.text.p, T_host, n, hipMemcpyHostToDevice, idx->stream));
+    idx->has_index = false;
+    rc = idx->b.build(n, max_suffix_length);
+    idx->has_index = (rc == 0);
+    return rc;
+}
+
+int sa_hip_index_build_device(sa_hip_index* idx, const void* T_dev, uint64_t n, uint32_t max_suffix_length) {
+    if (!idx || (!T_dev && n)) return fail(SA_HIP_EINVAL, "sa_hip_index_build_device: NULL argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    if (n > idx->b.n_max) return fail(SA_HIP_EINVAL, "sa_hip_index_build_device: n exceeds the index capacity");
+    if (n && T_dev != idx->b.text.p)
+        SA_HIP_CHECK(hipMemcpyAsync(idx->b.text.p, T_dev, n, hipMemcpyDeviceToDevice, idx->stream));
+    idx->has_index = false;
+    rc = idx->b.build(n, max_suffix_length);
+    idx->has_index = (rc == 0);
+    return rc;
+}
+
+static int load_common(sa_hip_index* idx, const void* T, const void* SA, uint64_t n, uint32_t L, hipMemcpyKind kind) {
+    std::lock_guard<std::mutex> g(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    if (n > idx->b.n_max) return fail(SA_HIP_EINVAL, "sa_hip_index_load: n exceeds the index capacity");
+    Builder& b = idx->b;
+    if ((rc = b.sa_own.ensure((size_t)(n ? n : 1) * 4))) return rc;
+    if (n) {
+        SA_HIP_CHECK(hipMemcpyAsync(b.text.p, T, n, kind, idx->stream));
+        SA_HIP_CHECK(hipMemcpyAsync(b.sa_own.p, SA, (size_t)n * 4, kind, idx->stream));
+    }
+    CodeMap map; u32 sigma; int bits;
+    if ((rc = b.prepare_text(n, map, sigma, bits))) return rc;
+    b.sa = b.sa_own.as<u32>();
+    b.max_suffix_length = L;
+    idx->has_index = true;
+    return 0;
+}
+
+int sa_hip_index_load(sa_hip_index* idx, const uint8_t* T_host, const uint32_t* SA_host, uint64_t n,
+                      uint32_t max_suffix_length) {
+    if (!idx || ((!T_host || !SA_host) && n)) return fail(SA_HIP_EINVAL, "sa_hip_index_load: NULL argument");
+    return load_common(idx, T_host, SA_host, n, max_suffix_length, hipMemcpyHostToDevice);
+}
+
+int sa_hip_index_load_device(sa_hip_index* idx, const void* T_dev, const void* SA_dev, uint64_t n,
+                             uint32_t max_suffix_length) {
+    if (!idx || ((!T_dev || !SA_dev) && n)) return fail(SA_HIP_EINVAL, "sa_hip_index_load_device: NULL argument");
+    return load_common(idx, T_dev, SA_dev, n, max_suffix_length, hipMemcpyDeviceToDevice);
+}
+
+uint64_t sa_hip_index_n(const sa_hip_index* idx) { return idx ? idx->b.n : 0; }
+uint32_t sa_hip_index_max_suffix_length(const sa_hip_index* idx) { return idx ? idx->b.max_suffix_length : 0; }
+const void* sa_hip_index_text_dev(const sa_hip_index* idx) { return idx ? idx->b.text.p : nullptr; }
+const void* sa_hip_index_sa_dev(const sa_hip_index* idx) { return (idx && idx->has_index) ? idx->b.sa : nullptr; }
+void* sa_hip_index_stream(const sa_hip_index* idx) { return idx ? (void*)idx->stream : nullptr; }
+
+int sa_hip_index_sync(sa_hip_index* idx) {
+    if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_sync: NULL index");
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+    return 0;
+}
+
+int sa_hip_index_get_sa_u32(sa_hip_index* idx, uint32_t* out_host) {
+    if (!idx || !idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_u32: no index");
+    if (!out_host && idx->b.n) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_u32: NULL output");
+    std::lock_guard<std::mutex> g(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    if (idx->b.n) SA_HIP_CHECK(hipMemcpyAsync(out_host, idx->b.sa, (size_t)idx->b.n * 4, hipMemcpyDeviceToHost, idx->stream));
+    SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+    return 0;
+}
+
+int sa_hip_index_get_sa_i64(sa_hip_index* idx, int64_t* out_host) {
+    if (!idx || !idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_i64: no index");
+    if (!out_host && idx->b.n) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_i64: NULL output");
+    std::lock_guard<std::mutex> g(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    const u64 n = idx->b.n;
+    if (n) {
+        // widen on the device in slabs (libsais64.c:6248-6259 does this on the CPU, in place)
+        const u64 slab = 64ull << 20;
+        if ((rc = idx->widen.ensure((size_t)(n < slab ? n : slab) * 8))) return rc;
+        for (u64 o = 0; o < n; o += slab) {
+            const u64 cnt = (n - o) < slab ? (n - o) : slab;
+            hipLaunchKernelGGL(widen_kernel, dim3(stream_grid(cnt, 1024)), dim3(256), 0, idx->stream, idx->b.sa + o, cnt,
+                               idx->widen.as<int64_t>());
+            SA_HIP_CHECK(hipMemcpyAsync(out_host + o, idx->widen.p, (size_t)cnt * 8, hipMemcpyDeviceToHost, idx->stream));
+            SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+        }
+    }
+    return 0;
+}
+
+int sa_hip_index_get_sa_range(sa_hip_index* idx, uint64_t first, uint64_t count, uint32_t* out_host) {
+    if (!idx || !idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: no index");
+    if (first > idx->b.n || count > idx->b.n - first) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: out of range");
+    if (!out_host && count) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: NULL output");
+    std::lock_guard<std::mutex> g(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    if (count) SA_HIP_CHECK(hipMemcpyAsync(out_host, idx->b.sa + first, (size_t)count * 4, hipMemcpyDeviceToHost, idx->stream));
+    SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+    return 0;
+}
+
+int sa_hip_index_get_freq(sa_hip_index* idx, uint64_t* freq256) {
+    if (!idx || !freq256) return fail(SA_HIP_EINVAL, "sa_hip_index_get_freq: NULL argument");
+    memcpy(freq256, idx->b.freq, sizeof idx->b.freq);
+    return 0;
+}
+
+int sa_hip_query_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_t* offsets, uint64_t Q,
+                       sa_hip_pair_u32* out) {
+    if (!idx || !idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_query_batch: no index");
+    if (Q == 0) return 0;
+    if (!offsets || !out) return fail(SA_HIP_EINVAL, "sa_hip_query_batch: NULL argument");
+    const u64 total = offsets[Q];
+    if (!patterns && total) return fail(SA_HIP_EINVAL, "sa_hip_query_batch: NULL patterns");
+    std::lock_guard<std::mutex> g(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    if ((rc = idx->q_pat.ensure((size_t)total + 64))) return rc;
+    if ((rc = idx->q_off.ensure((size_t)(Q + 1) * 8))) return rc;
+    if ((rc = idx->q_out.ensure((size_t)Q * sizeof(sa_hip_pair_u32)))) return rc;
+    if (total) SA_HIP_CHECK(hipMemcpyAsync(idx->q_pat.p, patterns, total, hipMemcpyHostToDevice, idx->stream));
+    SA_HIP_CHECK(hipMemsetAsync(idx->q_pat.as<u8>() + total, 0, 64, idx->stream));
+    SA_HIP_CHECK(hipMemcpyAsync(idx->q_off.p, offsets, (size_t)(Q + 1) * 8, hipMemcpyHostToDevice, idx->stream));
+    if ((rc = launch_query(idx, idx->q_pat.as<u8>(), idx->q_off.as<u64>(), Q, idx->q_out.as<sa_hip_pair_u32>()))) return rc;
+    SA_HIP_CHECK(hipMemcpyAsync(out, idx->q_out.p, (size_t)Q * sizeof(sa_hip_pair_u32), hipMemcpyDeviceToHost, idx->stream));
+    SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+    return 0;
+}
+
+int sa_hip_query_batch_device(sa_hip_index* idx, const void* patterns_dev, const void* offsets_dev, uint64_t Q,
+                              void* out_dev) {
+    if (!idx || !idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_query_batch_device: no index");
+    if (Q == 0) return 0;
+    if (!patterns_dev || !offsets_dev || !out_dev) return fail(SA_HIP_EINVAL, "sa_hip_query_batch_device: NULL argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    return launch_query(idx, (const u8*)patterns_dev, (const u64*)offsets_dev, Q, (sa_hip_pair_u32*)out_dev);
+}
+
+int sa_hip_index_build_stats(const sa_hip_index* idx, sa_hip_build_stats* out) {
+    if (!idx || !out) return fail(SA_HIP_EINVAL, "sa_hip_index_build_stats: NULL argument");
+    *out = idx->b.stats;
+    return 0;
+}
+
+int sa_hip_index_query_stats(const sa_hip_index* idx_c, sa_hip_query_stats* out) {
+    sa_hip_index* idx = const_cast<sa_hip_index*>(idx_c);
+    if (!idx || !out) return fail(SA_HIP_EINVAL, "sa_hip_index_query_stats: NULL argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    if (idx->qstats.kernel_ms < 0.0) {
+        SA_HIP_CHECK(hipEventSynchronize(idx->q_end));
+        float ms = 0.f;
+        SA_HIP_CHECK(hipEventElapsedTime(&ms, idx->q_begin, idx->q_end));
+        idx->qstats.kernel_ms = ms;
+    }
+    *out = idx->qstats;
+    return 0;
+}
+
+// ---- libsais-call-compatible wrappers --------------------------------------------------------------
+
+static int build_to_host(const uint8_t* T, uint64_t n, uint32_t L, TempIndex& t) {
+    int rc = sa_hip_index_create(&t.idx, n, 0);
+    if (rc) return rc;
+    return sa_hip_index_build(t.idx, T, n, L);
+}
+
+int32_t sa_hip_libsais_omp(const uint8_t* T, int32_t* SA, int32_t n, int32_t fs, int32_t* freq, int32_t threads) {
+    if (T == nullptr || SA == nullptr || n < 0 || fs < 0 || threads < 0) return fail(SA_HIP_EINVAL, "sa_hip_libsais: invalid arguments");
+    TempIndex t;
+    int rc = build_to_host(T, (uint64_t)n, 0, t);
+    if (rc) return rc;
+    rc = sa_hip_index_get_sa_u32(t.idx, reinterpret_cast<uint32_t*>(SA));
+    if (rc) return rc;
+    if (freq) for (int c = 0; c < 256; ++c) freq[c] = (int32_t)t.idx->b.freq[c];
+    return 0;
+}
+
+int32_t sa_hip_libsais(const uint8_t* T, int32_t* SA, int32_t n, int32_t fs, int32_t* freq) {
+    return sa_hip_libsais_omp(T, SA, n, fs, freq, 0);
+}
+
+int64_t sa_hip_libsais64_omp(const uint8_t* T, int64_t* SA, int64_t n, int64_t fs, int64_t* freq, int64_t threads) {
+    if (T == nullptr || SA == nullptr || n < 0 || fs < 0 || threads < 0) return fail(SA_HIP_EINVAL, "sa_hip_libsais64: invalid arguments");
+    if ((uint64_t)n > 0xFFFFFFFEull) return fail(SA_HIP_EINVAL, "sa_hip_libsais64: n exceeds 2^32 - 2 (single-GPU 32-bit pipeline)");
+    TempIndex t;
+    int rc = build_to_host(T, (uint64_t)n, 0, t);
+    if (rc) return rc;
+    rc = sa_hip_index_get_sa_i64(t.idx, SA);
+    if (rc) return rc;
+    if (freq) for (int c = 0; c < 256; ++c) freq[c] = (int64_t)t.idx->b.freq[c];
+    return 0;
+}
+
+int64_t sa_hip_libsais64(const uint8_t* T, int64_t* SA, int64_t n, int64_t fs, int64_t* freq) {
+    return sa_hip_libsais64_omp(T, SA, n, fs, freq, 0);
+}
+
+// ---- engine.c-call-compatible wrappers ---------------------------------------------------------------
+
+int sa_hip_construct_truncated_suffix_array(const char* text, sa_hip_SuffixArray_struct* s) {
+    if (!text || !s || (!s->suffix_array && s->n)) return fail(SA_HIP_EINVAL, "sa_hip_construct_truncated_suffix_array: NULL argument");
+    // engine.c:841: depth = min(max_suffix_length, n); 0 would mean "no order at all" there,
+    // which the device build expresses as L >= 1 only, so L == 0 degenerates to identity order.
+    if (s->max_suffix_length == 0) {
+        for (uint32_t i = 0; i < s->n; ++i) s->suffix_array[i] = i;
+        return 0;
+    }
+    TempIndex t;
+    int rc = build_to_host(reinterpret_cast<const uint8_t*>(text), s->n, s->max_suffix_length, t);
+    if (rc) return rc;
+    return sa_hip_index_get_sa_u32(t.idx, s->suffix_array);
+}
+
+sa_hip_pair_u32 sa_hip_get_substring_positions(const char* str, const sa_hip_SuffixArray_struct* s, const char* substring) {
+    sa_hip_pair_u32 r = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (!str || !s || !substring || (!s->suffix_array && s->n)) { fail(SA_HIP_EINVAL, "sa_hip_get_substring_positions: NULL argument"); return r; }
+    TempIndex t;
+    if (sa_hip_index_create(&t.idx, s->n, 0)) return r;
+    // max_suffix_length == 0 in the reference means cmp_length 0 (everything matches); the handle
+    // API uses 0 for "unlimited", so pass the pattern truncated accordingly.
+    const uint64_t m = strlen(substring);
+    const uint32_t L = s->max_suffix_length;
+    if (sa_hip_index_load(t.idx, reinterpret_cast<const uint8_t*>(str), s->suffix_array, s->n, L ? L : 1)) return r;
+    const uint64_t off[2] = {0, L ? m : 0};
+    if (sa_hip_query_batch(t.idx, reinterpret_cast<const uint8_t*>(substring), off, 1, &r)) {
+        r.first = r.second = 0xFFFFFFFFu;
+    }
+    return r;
+}
+
+int sa_hip_sort_pairs(uint64_t* keys, uint32_t* values, uint64_t n, int begin_bit, int end_bit, int device) {
+    if ((!keys && n) || begin_bit < 0 || end_bit > 64 || begin_bit > end_bit || n > 0xFFFFFFFEull)
+        return fail(SA_HIP_EINVAL, "sa_hip_sort_pairs: invalid arguments");
+    if (n == 0 || begin_bit == end_bit) return 0;
+    int rc = set_device(device);
+    if (rc) return rc;
+    hipStream_t stream;
+    SA_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    RadixWorkspace ws;
+    DevBuf k0, k1, v0, v1;
+    rc = ws.init(n);
+    if (!rc) rc = k0.ensure(n * 8);
+    if (!rc) rc = k1.ensure(n * 8);
+    if (!rc) rc = v0.ensure(n * 4);
+    if (!rc) rc = v1.ensure(n * 4);
+    u64* kr = nullptr; u32* vr = nullptr;
+    auto body = [&]() -> int {
+        SA_HIP_CHECK(hipMemcpyAsync(k0.p, keys, n * 8, hipMemcpyHostToDevice, stream));
+        if (values) SA_HIP_CHECK(hipMemcpyAsync(v0.p, values, n * 4, hipMemcpyHostToDevice, stream));
+        int r = radix_sort_pairs(ws, stream, k0.as<u64>(), v0.as<u32>(), k1.as<u64>(), v1.as<u32>(), (u32)n, begin_bit,
+                                 end_bit, values == nullptr, &kr, &vr);
+        if (r) return r;
+        SA_HIP_CHECK(hipMemcpyAsync(keys, kr, n * 8, hipMemcpyDeviceToHost, stream));
+        if (values) SA_HIP_CHECK(hipMemcpyAsync(values, vr, n * 4, hipMemcpyDeviceToHost, stream));
+        DeviceStatus st;
+        SA_HIP_CHECK(hipMemcpyAsync(&st, ws.dstat, sizeof st, hipMemcpyDeviceToHost, stream));
+        SA_HIP_CHECK(hipStreamSynchronize(stream));
+        if (st.error) return fail(SA_HIP_EINTERNAL, "device look-back spin limit expired");
+        return ws.timer.flush();
+    };
+    if (!rc) rc = body();
+    (void)hipStreamSynchronize(stream);
+    k0.release(); k1.release(); v0.release(); v1.release();
+    ws.destroy();
+    (void)hipStreamDestroy(stream);
+    return rc;
+}
+
+void sa_hip_synth_uniform27(uint8_t* out, uint64_t n, uint64_t seed) {
+    // xorshift64 (13,7,17), symbol = (s >> 33) % 27, 26 -> '\n'
+    uint64_t s = seed ? seed : 88172645463325252ull;
+    for (uint64_t i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const uint32_t v = (uint32_t)((s >> 33) % 27u);
+        out[i] = (uint8_t)(v == 26 ? '\n' : 'a' + v);
+    }
+}
+
+}  // extern "C"

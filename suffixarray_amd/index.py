@@ -1,0 +1,150 @@
+"""Host-side mirror of the reference's Python class (suffix_array/suffix_array.pyx:110-267,
+README.md:13-50) on top of the C ABI.  Same names, argument meaning and defaults:
+
+    SuffixArray(documents=[...], max_suffix_length=32).query_records("the quick brown fox")
+    SuffixArray(csv_file=..., search_column=..., max_suffix_length=32).query_records("netflix")
+
+plus the batched entry point the device path exists for: query_records_batch / query_ranges.
+Decisions where the reference snapshot cannot arbitrate (SURVEY.md 0.3, 7 "hard parts") are
+listed in DESIGN.md: documents are returned in their original case, one record per matching
+document (no duplicates), CSV header row is not indexed.
+"""
+import csv as _csv
+import io
+import os
+
+import numpy as np
+
+from . import _capi
+
+
+def _ascii_lower(b: bytes) -> bytes:
+    """pyx:103-107 lowercase_string: only bytes 65..90 are changed."""
+    return b.translate(_LOWER)
+
+
+_LOWER = bytes((c + 32) if 65 <= c <= 90 else c for c in range(256))
+
+
+class SuffixArray:
+    def __init__(self, documents=None, csv_file=None, search_column=None, max_suffix_length: int = 64,
+                 device: int = 0):
+        if max_suffix_length is None or int(max_suffix_length) < 1:
+            raise ValueError("max_suffix_length must be >= 1")
+        self.max_suffix_length = int(max_suffix_length)
+        self.device = int(device)
+        self._index = None
+        self._mode = None
+        self.columns = None
+        if documents is not None and csv_file is not None:
+            raise ValueError("pass either documents= or csv_file=, not both")
+        if documents is not None:
+            self.construct_truncated_suffix_array_documents(documents)
+        elif csv_file is not None:
+            if search_column is None:
+                raise ValueError("search_column is required with csv_file")
+            self.construct_truncated_suffix_array_from_csv(csv_file, search_column)
+
+    # -- construction ---------------------------------------------------------------------------
+    def construct_truncated_suffix_array_documents(self, documents):
+        """pyx:129-180: text = '\\n'.join(documents), lower-cased, one truncated SA over it."""
+        if not isinstance(documents, list):
+            try:
+                documents = list(documents)
+            except Exception:
+                raise ValueError("Documents must be a list of strings")
+        self._documents = documents
+        encoded = [d.encode("utf-8") for d in documents]
+        text = _ascii_lower(b"\n".join(encoded))
+        lens = np.fromiter((len(e) for e in encoded), dtype=np.int64, count=len(encoded))
+        # start offset of every document in the joined text
+        self._row_starts = np.concatenate([[0], np.cumsum(lens + 1)[:-1]]).astype(np.int64) if len(encoded) else np.zeros(0, np.int64)
+        self._set_text(text)
+        self._mode = "documents"
+
+    def construct_truncated_suffix_array_from_csv(self, filename: str, search_column: str):
+        """pyx:183-207 / engine.c:461-654: index one column of a CSV file (RFC-4180 quoting)."""
+        from .csv_ingest import extract_column
+        self.csv_filename = filename
+        col = extract_column(filename, search_column)
+        self.columns = col.columns
+        self._row_starts = col.text_row_starts      # offset of every row's field in the column text
+        self._row_file_offsets = col.row_file_offsets
+        self._set_text(col.text)
+        self._mode = "csv"
+
+    def _set_text(self, text: bytes):
+        if len(text) > 0xFFFFFFFE:
+            raise ValueError("text exceeds 2^32 - 2 bytes (one index per device)")
+        self._text_len = len(text)
+        if self._index is not None:
+            self._index.close()
+        self._index = _capi.DeviceIndex(max(len(text), 1), self.device)
+        self._index.build(text, self.max_suffix_length)
+
+    # -- query ------------------------------------------------------------------------------------
+    def query_ranges(self, substrings):
+        """Batched get_substring_positions: (first, second) per pattern, reference conventions."""
+        pats = [_ascii_lower(s.encode("utf-8")) if isinstance(s, str) else _ascii_lower(bytes(s)) for s in substrings]
+        return self._index.query_batch(pats)
+
+    def _rows_for_range(self, first, second, k):
+        if first == _capi.UINT32_MAX or ((second - first + 1) & 0xFFFFFFFF) == 0:
+            return np.zeros(0, np.int64)
+        count = int(second) - int(first) + 1
+        rows = []
+        seen = set()
+        # hits arrive in SA order; walk them in slabs until k distinct rows are found
+        pos = int(first)
+        end = int(first) + count
+        slab = max(4 * k, 1024)
+        while pos < end and len(rows) < k:
+            take = min(slab, end - pos)
+            hits = self._index.sa_range(pos, take).astype(np.int64)
+            ids = np.searchsorted(self._row_starts, hits, side="right") - 1
+            for r in ids.tolist():
+                if r not in seen:
+                    seen.add(r)
+                    rows.append(r)
+                    if len(rows) == k:
+                        break
+            pos += take
+        return np.asarray(rows, dtype=np.int64)
+
+    def _materialise(self, rows):
+        if self._mode == "documents":
+            return [self._documents[r] for r in rows.tolist()]
+        out = []
+        with open(self.csv_filename, "rb") as f:
+            for r in rows.tolist():
+                f.seek(int(self._row_file_offsets[r]))
+                n = int(self._row_file_offsets[r + 1] - self._row_file_offsets[r])
+                line = f.read(n).decode("utf-8", "replace")
+                rec = next(_csv.reader(io.StringIO(line)))
+                out.append(dict(zip(self.columns, rec)))
+        return out
+
+    def query_records(self, substring: str, k: int = 1000):
+        """pyx:209-267: records containing `substring` (case-insensitive ASCII), at most k."""
+        if substring == "":
+            return []
+        return self.query_records_batch([substring], k)[0]
+
+    def query_records_batch(self, substrings, k: int = 1000):
+        if self._index is None:
+            raise RuntimeError("index not built")
+        res = [None] * len(substrings)
+        live = [i for i, s in enumerate(substrings) if s != ""]
+        ranges = self.query_ranges([substrings[i] for i in live]) if live else []
+        for i in range(len(substrings)):
+            if substrings[i] == "":
+                res[i] = []
+        for j, i in enumerate(live):
+            rows = self._rows_for_range(int(ranges[j]["first"]), int(ranges[j]["second"]), k)
+            res[i] = self._materialise(rows)
+        return res
+
+    def close(self):
+        if self._index is not None:
+            self._index.close()
+            self._index = None

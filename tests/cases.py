@@ -1,0 +1,49 @@
+"""Shared input cases for the parity tests (same seeds on CPU and GPU)."""
+import numpy as np
+
+from suffixarray_amd import synth
+
+
+def small_texts():
+    rng = np.random.default_rng(42)
+    c = {
+        "banana": np.frombuffer(b"banana", np.uint8),
+        "mississippi": np.frombuffer(b"mississippi", np.uint8),
+        "len1": np.frombuffer(b"z", np.uint8),
+        "len2": np.frombuffer(b"ba", np.uint8),
+        "aa": np.frombuffer(b"aa", np.uint8),
+        "all_a_5000": synth.all_same(5000),
+        "all_a_70000": synth.all_same(70000),
+        "ab_3000": synth.periodic(6000, 2),
+        "abc_2000": synth.periodic(6000, 3),
+        "period7": synth.periodic(50001, 7),
+        "fib": synth.fibonacci(46368),
+        "perm256": np.tile(np.arange(256, dtype=np.uint8), 20),
+        "highbit": np.tile(np.frombuffer(bytes([255, 0, 128, 255, 255, 0, 0, 1]), np.uint8), 300),
+        "zeros": np.zeros(3000, np.uint8),
+        "with_nul": np.frombuffer(b"ab\x00ab\x00\x00abab\x00", np.uint8),
+    }
+    for n in (3, 63, 64, 65, 4095, 4096, 4097, 8193, 65535, 65536, 65537):
+        c[f"r27_{n}"] = rng.integers(97, 124, n, dtype=np.uint8)
+    for sig in (2, 4, 256):
+        c[f"r{sig}_30000"] = rng.integers(0, sig, 30000, dtype=np.uint8)
+    c["d1_300k"] = synth.d1_uniform27(300_000)
+    c["d2_300k"] = synth.d2_words(300_000)
+    # long repeats: a random block repeated, forces doubling rounds on a large active set
+    blk = rng.integers(97, 101, 5000, dtype=np.uint8)
+    c["repeat_block"] = np.tile(blk, 12)
+    return c
+
+
+def query_patterns(text, count, rng, maxlen=40):
+    n = text.size
+    pats = []
+    for i in range(count):
+        m = int(rng.integers(1, maxlen + 1))
+        if i % 2 == 0 and n > m:
+            p = int(rng.integers(0, n - m))
+            pats.append(bytes(text[p:p + m]))
+        else:
+            pats.append(bytes(rng.integers(97, 123, m, dtype=np.uint8)))
+    pats += [b"", b"a", b"zzzzzzzz", bytes([255]) * 3, bytes([1]), bytes(text[-5:]), bytes(text[-1:]), bytes(text[:7])]
+    return pats

@@ -1,0 +1,47 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle.oracle import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    from oracle.oracle import Ref
+    if not Ref.available():
+        pytest.skip("oracle/_ref/libsa_ref.so not built (reference sources absent)")
+    return Ref()
+
+
+@pytest.fixture(scope="session")
+def capi():
+    """The C ABI; building is part of the contract (hipcc cross-compiles without a GPU)."""
+    from suffixarray_amd.build import build_lib
+    build_lib()
+    from suffixarray_amd import _capi
+    _capi.lib()
+    return _capi
+
+
+@pytest.fixture(scope="session")
+def gpu(capi):
+    n = capi.lib().sa_hip_device_count()
+    if n < 1:
+        pytest.fail("gpu test selected but no HIP device is usable: " + capi.lib().sa_hip_last_error().decode())
+    return capi

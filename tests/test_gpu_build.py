@@ -1,0 +1,118 @@
+"""GPU: suffix-array construction through the C ABI, bit-exact against the oracle and the
+golden vectors produced by the reference (libsais 2.8.4)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from conftest import GOLDEN
+from test_oracle import check_truncated_order
+
+pytestmark = pytest.mark.gpu
+
+
+def test_small_cases_bit_exact(gpu, oracle):
+    texts = cases.small_texts()
+    nmax = max(t.size for t in texts.values())
+    with gpu.DeviceIndex(nmax, 0) as idx:
+        for name, t in texts.items():
+            idx.build(t)
+            got = idx.sa_u32()
+            exp = oracle.sais(t).astype(np.uint32)
+            assert np.array_equal(got, exp), (name, idx.build_stats())
+            f = idx.freq()
+            assert np.array_equal(f, np.bincount(t, minlength=256).astype(np.uint64)), name
+
+
+def test_golden_small(gpu):
+    g = np.load(os.path.join(GOLDEN, "golden_small.npz"), allow_pickle=False)
+    with gpu.DeviceIndex(1 << 17, 0) as idx:
+        for name in g["names"]:
+            t, sa = g[f"text__{name}"], g[f"sa__{name}"]
+            idx.build(t)
+            assert np.array_equal(idx.sa_u32(), sa.astype(np.uint32)), name
+            assert np.array_equal(idx.sa_i64(), sa.astype(np.int64)), name
+
+
+def test_golden_1mb_digest(gpu):
+    g = np.load(os.path.join(GOLDEN, "golden_1mb.npz"), allow_pickle=False)
+    with gpu.DeviceIndex(1 << 20, 0) as idx:
+        for name in g["names"]:
+            t = g[f"text__{name}"]
+            idx.build(t)
+            d = hashlib.sha256(idx.sa_u32().astype("<i4").tobytes()).hexdigest()
+            assert d == str(g[f"sa_sha256__{name}"][0]), (name, idx.build_stats())
+
+
+def test_empty_and_tiny(gpu):
+    with gpu.DeviceIndex(16, 0) as idx:
+        idx.build(np.zeros(0, np.uint8))
+        assert idx.sa_u32().size == 0
+        idx.build(np.frombuffer(b"q", np.uint8))
+        assert idx.sa_u32().tolist() == [0]
+        idx.build(np.frombuffer(b"ba", np.uint8))
+        assert idx.sa_u32().tolist() == [1, 0]
+
+
+def test_libsais_compatible_wrappers(gpu, oracle):
+    t = cases.small_texts()["d2_300k"]
+    sa, freq = gpu.libsais(t, want_freq=True)
+    exp = oracle.sais(t)
+    assert sa.dtype == np.int32 and np.array_equal(sa, exp)
+    assert np.array_equal(freq, np.bincount(t, minlength=256).astype(np.int32))
+    sa64 = gpu.libsais64(t)
+    assert sa64.dtype == np.int64 and np.array_equal(sa64, exp.astype(np.int64))
+    # libsais argument validation: -1 on bad arguments (libsais.c:6620-6623)
+    lib = gpu.lib()
+    buf = np.zeros(4, np.int32)
+    assert lib.sa_hip_libsais(None, buf.ctypes.data, 4, 0, None) == -1
+    assert lib.sa_hip_libsais(t.ctypes.data, None, 4, 0, None) == -1
+    assert lib.sa_hip_libsais(t.ctypes.data, buf.ctypes.data, -1, 0, None) == -1
+    assert lib.sa_hip_libsais(t.ctypes.data, buf.ctypes.data, 4, -1, None) == -1
+    assert lib.sa_hip_libsais_omp(t.ctypes.data, buf.ctypes.data, 4, 0, None, -1) == -1
+    assert lib.sa_hip_libsais_omp(t.ctypes.data, buf.ctypes.data, 4, 0, None, 3) == 0
+    assert np.array_equal(buf, oracle.sais(t[:4]))
+
+
+def test_truncated_mode_bit_exact_vs_oracle(gpu, oracle):
+    texts = cases.small_texts()
+    nmax = max(t.size for t in texts.values())
+    with gpu.DeviceIndex(nmax, 0) as idx:
+        for name, t in texts.items():
+            for L in (1, 5, 32, 64):
+                idx.build(t, L)
+                got = idx.sa_u32()
+                assert np.array_equal(got, oracle.truncated_sa(t, L)), (name, L, idx.build_stats())
+    t = texts["d2_300k"]
+    sa = gpu.construct_truncated_suffix_array(t, 32)
+    check_truncated_order(t, sa, 32)
+
+
+def test_doubling_path_is_exercised(gpu, oracle):
+    """Long repeats must go through chunk rounds AND doubling rounds."""
+    t = cases.small_texts()["repeat_block"]
+    with gpu.DeviceIndex(t.size, 0) as idx:
+        idx.build(t)
+        st = idx.build_stats()
+        assert st["doubling_rounds"] >= 1 and st["chunk_rounds"] >= 1, st
+        assert np.array_equal(idx.sa_u32(), oracle.sais(t).astype(np.uint32))
+
+
+def test_medium_d1_and_words(gpu, oracle):
+    from suffixarray_amd import synth
+    for t in (synth.d1_uniform27(10_000_000), synth.d2_words(10_000_000)):
+        with gpu.DeviceIndex(t.size, 0) as idx:
+            idx.build(t)
+            got = idx.sa_u32()
+            assert np.array_equal(got, oracle.sais(t).astype(np.uint32)), idx.build_stats()
+
+
+def test_rebuild_same_handle_is_idempotent(gpu):
+    from suffixarray_amd import synth
+    t = synth.d1_uniform27(1_000_000)
+    with gpu.DeviceIndex(t.size, 0) as idx:
+        a = idx.build(t).sa_u32().copy()
+        b = idx.build(t).sa_u32().copy()
+        assert np.array_equal(a, b)

@@ -1,0 +1,118 @@
+"""GPU: batched substring query through the C ABI against the oracle restatement of
+get_substring_positions (engine.c:869-918) and the reference-generated golden ranges."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_golden_readme(gpu):
+    g = np.load(os.path.join(GOLDEN, "golden_readme.npz"), allow_pickle=False)
+    t, sa = g["text"], g["sa"].astype(np.uint32)
+    L = int(g["max_suffix_length"][0])
+    pats = [bytes(p) for p in g["patterns"]]
+    with gpu.DeviceIndex(t.size, 0) as idx:
+        idx.load(t, sa, L)
+        assert np.array_equal(idx.query_batch(pats), g["ranges"])
+        idx.build(t, L)   # truncated device build gives the same ranges
+        assert np.array_equal(idx.query_batch(pats), g["ranges"])
+        idx.build(t, 0)   # and so does the full suffix array
+        assert np.array_equal(idx.query_batch(pats), g["ranges"])
+
+
+def test_golden_1mb_ranges(gpu):
+    g = np.load(os.path.join(GOLDEN, "golden_1mb.npz"), allow_pickle=False)
+    L = int(g["max_suffix_length"][0])
+    with gpu.DeviceIndex(1 << 20, 0) as idx:
+        for name in g["names"]:
+            t = g[f"text__{name}"]
+            pats = [bytes(p) for p in g[f"patterns__{name}"]]
+            idx.build(t, L)
+            got = idx.query_batch(pats)
+            assert np.array_equal(got, g[f"ranges__{name}"]), name
+            # hit sets, not only ranges
+            sa = idx.sa_u32()
+            for q, (f, s) in list(zip(pats, got))[:200]:
+                if f != 0xFFFFFFFF and s != 0xFFFFFFFF and s >= f:
+                    for p in sa[f:s + 1][:20]:
+                        assert bytes(t[p:p + min(len(q), L)]) == q[:L]
+
+
+def test_small_cases_vs_oracle(gpu, oracle):
+    rng = np.random.default_rng(123)
+    texts = cases.small_texts()
+    nmax = max(t.size for t in texts.values())
+    with gpu.DeviceIndex(nmax, 0) as idx:
+        for name, t in texts.items():
+            sa = oracle.sais(t).astype(np.uint32)
+            pats = cases.query_patterns(t, 300, rng)
+            for L in (0, 4, 32):
+                idx.load(t, sa, L)
+                got = idx.query_batch(pats)
+                exp = oracle.query_batch(t, sa, L if L else 0xFFFFFFFF, pats)
+                assert np.array_equal(got, exp), (name, L)
+
+
+def test_empty_batch_and_empty_text(gpu):
+    with gpu.DeviceIndex(64, 0) as idx:
+        idx.build(np.frombuffer(b"hello\nworld\n", np.uint8))
+        assert idx.query_batch([]).size == 0
+        r = idx.query_batch([b""])
+        assert tuple(r[0]) == (0, 11)
+        idx.build(np.zeros(0, np.uint8))
+        r = idx.query_batch([b"a", b""])
+        assert tuple(r[0]) == (0xFFFFFFFF, 0xFFFFFFFF) and tuple(r[1]) == (0xFFFFFFFF, 0xFFFFFFFF)
+
+
+def test_single_query_wrapper(gpu, oracle):
+    t = np.frombuffer(b"the quick brown fox\njumps over the lazy dog\n", np.uint8)
+    sa = oracle.sais(t).astype(np.uint32)
+    for q in (b"the", b"fox", b"zzz", b"q", b"the lazy dog\n"):
+        assert gpu.get_substring_positions(t, sa, 32, q) == oracle.query(t, sa, 32, q), q
+
+
+def test_large_batch_d1(gpu, oracle):
+    from suffixarray_amd import synth
+    t = synth.d1_uniform27(5_000_000)
+    buf, off = synth.query_batch(t, 200_000, 16)
+    with gpu.DeviceIndex(t.size, 0) as idx:
+        idx.build(t)
+        got = idx.query_batch((buf, off))
+        sa = idx.sa_u32()
+    exp = oracle.query_batch(t, sa, 0xFFFFFFFF, (buf, off))
+    assert np.array_equal(got, exp)
+    hits = ((got["second"] - got["first"] + 1) & 0xFFFFFFFF) > 0
+    assert 0.05 < hits.mean() < 0.95
+
+
+def test_python_api_documents(gpu):
+    from suffixarray_amd import SuffixArray
+    docs = ["The quick brown fox jumps over the lazy dog",
+            "I am going to the store to buy some milk",
+            "Uhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhh"]
+    s = SuffixArray(documents=docs, max_suffix_length=32)
+    assert s.query_records("the quick brown fox") == [docs[0]]
+    assert sorted(s.query_records("the")) == sorted(docs[:2])
+    assert s.query_records("MILK") == [docs[1]]
+    assert s.query_records("zzz") == []
+    assert s.query_records("") == []
+    assert s.query_records("the", k=1) in ([docs[0]], [docs[1]])
+    assert s.query_records_batch(["milk", "", "uhh"]) == [[docs[1]], [], [docs[2]]]
+    s.close()
+
+
+def test_python_api_csv(gpu, tmp_path):
+    from suffixarray_amd import SuffixArray
+    p = tmp_path / "companies.csv"
+    p.write_text('id,company_name,country\n1,Netflix,US\n2,"Acme, Inc.",US\n3,Initech,DE\n4,netflix studios,US\n')
+    s = SuffixArray(csv_file=str(p), search_column="company_name", max_suffix_length=32)
+    recs = s.query_records("netflix")
+    assert sorted(r["id"] for r in recs) == ["1", "4"]
+    assert s.query_records("acme, inc")[0] == {"id": "2", "company_name": "Acme, Inc.", "country": "US"}
+    assert s.query_records("company_name") == []   # header row is not indexed
+    s.close()

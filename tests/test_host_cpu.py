@@ -1,0 +1,87 @@
+"""CPU: the C ABI loads and exports every declared symbol (no compute without a GPU), the
+pipeline model (host logic of the device build) matches the oracle, host helpers behave."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cases
+from pipeline_model import build_sa_model
+from test_oracle import check_truncated_order
+
+
+def test_library_exports_every_declared_symbol(capi):
+    lib = capi.lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "sa_hip.h")).read()
+    declared = set(re.findall(r"\b(sa_hip_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(capi.EXPORTS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert b"gfx950" in lib.sa_hip_version()
+
+
+def test_struct_layouts_match_reference_abi(capi):
+    import ctypes as C
+    assert C.sizeof(capi.SuffixArrayStruct) == 40   # engine.h:123-130
+    assert C.sizeof(capi.PairU32) == 8              # engine.h:219-222
+
+
+def test_no_gpu_means_loud_failure(capi):
+    """Without a device every compute entry point must fail, never fall back."""
+    if capi.lib().sa_hip_device_count() >= 1:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(capi.SaHipError):
+        capi.DeviceIndex(1024, 0)
+    with pytest.raises(capi.SaHipError):
+        capi.libsais(b"banana")
+
+
+def test_synth_d1_matches_definition(capi):
+    a = capi.synth_uniform27(1000)
+    s = 88172645463325252
+    m = (1 << 64) - 1
+    exp = []
+    for _ in range(1000):
+        s ^= (s << 13) & m
+        s ^= s >> 7
+        s ^= (s << 17) & m
+        v = (s >> 33) % 27
+        exp.append(10 if v == 26 else 97 + v)
+    assert a.tolist() == exp
+
+
+def test_pipeline_model_full(oracle):
+    for name, t in cases.small_texts().items():
+        if t.size > 70000 or t.size == 0:
+            continue
+        exp = oracle.sais(t).astype(np.uint32)
+        for cr in (0, 2):
+            got = build_sa_model(t, chunk_rounds_before_doubling=cr)
+            assert np.array_equal(got, exp), (name, cr)
+
+
+def test_pipeline_model_truncated(oracle):
+    for name, t in cases.small_texts().items():
+        if t.size > 20000 or t.size == 0:
+            continue
+        for L in (1, 2, 5, 32, 64):
+            got = build_sa_model(t, max_suffix_length=L)
+            assert np.array_equal(got, oracle.truncated_sa(t, L)), (name, L)
+            check_truncated_order(t, got, L)
+
+
+def test_csv_ingest(tmp_path):
+    from suffixarray_amd.csv_ingest import extract_column
+    p = tmp_path / "c.csv"
+    p.write_text('id,name,country\n1,Netflix,US\n2,"Acme, Inc.",US\n3,"Multi\nLine ""Q""",DE\n4,netflix studios,US\n')
+    col = extract_column(str(p), "name")
+    assert col.columns == ["id", "name", "country"]
+    assert col.text == b'netflix\nacme, inc.\nmulti line "q"\nnetflix studios\n'
+    assert col.text_row_starts.tolist() == [0, 8, 19, 34]
+    data = p.read_bytes()
+    assert data[col.row_file_offsets[1]:col.row_file_offsets[2]] == b'2,"Acme, Inc.",US\n'
+    with pytest.raises(ValueError):
+        extract_column(str(p), "nope")
