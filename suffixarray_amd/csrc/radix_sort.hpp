@@ -1,19 +1,37 @@
 // radix_sort.hpp -- hand-written LSD radix sort of (u64 key, u32 value) records for gfx950.
 //
-// One-sweep structure: ONE histogram pre-pass over all digits, then per 8-bit digit ONE kernel
-// that reads every record once and writes it once.  Inside a pass each workgroup
-//   1. takes the next tile id from an atomic ticket (tiles start in ticket order, so every
-//      predecessor tile is already resident -> look-back cannot deadlock),
+// One-sweep structure: per 8-bit digit ONE kernel that reads every record once and writes it
+// once; digit histograms come for free from the kernel that produced the input (the key
+// generator for pass 0, the previous pass for every later pass).
+//
+// XCD-aware decomposition (MI355X: 8 XCDs, 256 CUs, ~1000 tiles in flight, a poll of another
+// workgroup's status word is a ~1 us fabric round trip): a single decoupled look-back chain over
+// all tiles costs more than moving the data (measured: 58 % of the pass, tools/sortbench.hip).
+// The input of every pass is therefore cut into NCHUNK = 8 contiguous chunks of tiles with
+//   * a digit histogram PER CHUNK  -> digit_base[chunk][digit] is known before the pass starts,
+//   * a tile ticket PER CHUNK      -> tiles of a chunk start in order,
+//   * a look-back chain PER CHUNK  -> 8 independent chains, each 1/8 as long and 1/8 as busy.
+// A workgroup takes its tile from the chunk of the XCD it runs on (HW_REG_XCC_ID) and steals
+// from the other chunks when its own is exhausted; placement changes speed only, any workgroup
+// may process any tile.  Because pass p+1 reads the records in the order pass p wrote them, the
+// per-chunk histogram of pass p+1 is accumulated BY pass p: while a tile's keys sit in LDS with
+// their destination index known, the workgroup counts (destination chunk, next digit) pairs in
+// LDS and flushes the non-zero bins with global atomics.
+//
+// Inside a pass each workgroup
+//   1. takes the next tile of a chunk from that chunk's atomic ticket (tiles of a chunk start in
+//      ticket order, so every predecessor is already resident -> look-back cannot deadlock),
 //   2. loads its tile wave-striped (64 lanes x 8 B = 512 B per load instruction),
 //   3. ranks its keys per wave with __ballot match masks (64-wide; 8 ballots per key) and
 //      per-wave digit counters in LDS -- no LDS atomics, stable by construction,
 //   4. publishes its 256 digit counts as 8-byte {epoch,flag,count} granules (one relaxed
-//      agent-scope store each; the data IS the flag, cdna_hip_programming.md G16/R2) and
-//      resolves its exclusive prefix by decoupled look-back over predecessor tiles
-//      (relaxed agent-scope loads; every spin is bounded and sets DeviceStatus.error),
-//   5. reorders keys (then values) through LDS so that each digit's run leaves the CU as
-//      contiguous global stores.
-// Algorithmic bytes per pass over M records: 2*M*(8+4); the pre-pass adds 8*M.
+//      agent-scope store each; the data IS the flag, cdna_hip_programming.md G16/R2), reorders
+//      its keys through LDS, then resolves its exclusive prefix by decoupled look-back over the
+//      predecessor tiles of its chunk, LB_WINDOW polls in flight per lane (relaxed agent-scope
+//      loads; every spin is bounded and sets DeviceStatus.error),
+//   5. streams keys (then values) out of LDS so that each digit's run leaves the CU as contiguous
+//      global stores, counting the next pass's (chunk, digit) histogram on the way.
+// Algorithmic bytes per pass over M records: 2*M*(8+4).
 //
 // This replaces, by function only, the bucket placement / induced-sorting scans of the
 // reference's libsais (libsais.c:1542-1614, 2110-2141, 2942-2975): same output order, no
@@ -25,10 +43,11 @@ namespace sa {
 
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
-constexpr int SORT_BLOCK = 256;   // 4 waves
+constexpr int NCHUNK = 8;         // look-back chains per pass = XCDs
 constexpr int SORT_ITEMS = 16;    // records per thread
-constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;  // 4096 records = 48 KB of (key,value)
+constexpr int MAX_PASSES = 8;
 constexpr u32 SPIN_LIMIT = 1u << 22;
+constexpr int LB_WINDOW = 8;      // look-back polls in flight per lane
 
 // tile status granule: [63:34] epoch | [33:32] flag | [31:0] count
 constexpr u64 FLAG_AGG = 1, FLAG_INCL = 2;
@@ -36,48 +55,101 @@ __device__ __forceinline__ u64 pack_status(u32 epoch, u64 flag, u32 v) {
     return ((u64)epoch << 34) | (flag << 32) | (u64)v;
 }
 
+__device__ __forceinline__ u32 xcc_id() {
+    u32 x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 7u;
+}
+
+// Geometry of one sort: chunk c = tiles [c*tpc, min((c+1)*tpc, tiles)).
+struct SortGeom {
+    u32 n;
+    u32 tile;        // records per tile (power of two)
+    u32 tile_shift;  // log2(tile)
+    u32 tiles;       // total tiles
+    u32 tpc;         // tiles per chunk
+};
+inline SortGeom make_geom(u32 n, u32 tile) {
+    SortGeom g;
+    g.n = n;
+    g.tile = tile;
+    g.tile_shift = 0;
+    while ((1u << g.tile_shift) < tile) ++g.tile_shift;
+    g.tiles = div_up(n, tile);
+    g.tpc = div_up(g.tiles ? g.tiles : 1, NCHUNK);
+    return g;
+}
+// chunk of a tile index: number of chunk boundaries at or below it (7 compares, exact, no division)
+__host__ __device__ __forceinline__ u32 chunk_of_tile(u32 t, u32 tpc) {
+    u32 c = 0;
+#pragma unroll
+    for (u32 k = 1; k < (u32)NCHUNK; ++k) c += (t >= k * tpc) ? 1u : 0u;
+    return c;
+}
+
 struct SortPassArgs {
     const u64* keys_in;
     const u32* vals_in;   // nullptr: value = record position (iota), first pass of a build
     u64* keys_out;
     u32* vals_out;
-    u32 n;
+    SortGeom g;
     int shift;
     u32 mask;
-    const u32* digit_base;  // [RADIX] exclusive global offsets of this pass
+    int next_shift;         // digit of the next pass; < 0: this is the last pass
+    u32 next_mask;
+    const u32* digit_base;  // [NCHUNK][RADIX] exclusive global offsets of this pass
+    u32* next_hist;         // [NCHUNK][RADIX] histogram of the next pass (zeroed by the host)
     u64* status;            // [tiles][RADIX]
-    u32* ticket;            // tile ticket counter of this pass (zeroed by the host)
+    u32* ticket;            // [NCHUNK] tile tickets of this pass (zeroed by the host)
     u32 epoch;
     DeviceStatus* dstat;
+    int home_mode;          // 0: home chunk = XCC id (product); 1: chunk 0; 2: blockIdx & 7 (tools/sortbench.hip)
 };
 
-// ---- histogram pre-pass: all digits of [begin_bit, begin_bit + 8*npasses) at once -------------
-__global__ __launch_bounds__(256) void radix_hist_kernel(const u64* __restrict__ keys, u32 n, int begin_bit,
-                                                         int npasses, u32 last_mask, u32* __restrict__ ghist) {
-    __shared__ u32 s_h[8 * RADIX];
-    for (int i = threadIdx.x; i < npasses * RADIX; i += blockDim.x) s_h[i] = 0;
+// ---- pass-0 histogram: digit [shift, shift+8) per chunk of the INPUT order ---------------------------
+// hist layout: [chunk][RADIX].  Every workgroup owns a contiguous range of tiles so that it crosses
+// a chunk boundary at most a few times (LDS histogram flushed at each crossing).
+__device__ __forceinline__ void hist_flush(u32* s_h, u32* hist, u32 chunk) {
     __syncthreads();
-    const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const u64 k = keys[i];
-        for (int p = 0; p < npasses; ++p) {
-            u32 d = (u32)(k >> (begin_bit + RADIX_BITS * p)) & (RADIX - 1);
-            if (p == npasses - 1) d &= last_mask;
-            atomicAdd(&s_h[p * RADIX + d], 1u);
+    for (int d = threadIdx.x; d < RADIX; d += blockDim.x) {
+        const u32 v = s_h[d];
+        if (v) {
+            atomicAdd(&hist[chunk * RADIX + d], v);
+            s_h[d] = 0;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < npasses * RADIX; i += blockDim.x) {
-        const u32 v = s_h[i];
-        if (v) atomicAdd(&ghist[i], v);
-    }
 }
 
-// exclusive scan of each pass's 256 bins; grid = npasses, block = 256
-__global__ __launch_bounds__(256) void radix_scan_hist_kernel(const u32* __restrict__ ghist, u32* __restrict__ gbase) {
+__global__ __launch_bounds__(256) void radix_hist_kernel(const u64* __restrict__ keys, SortGeom g, int shift,
+                                                         u32 mask, u32* __restrict__ hist) {
+    __shared__ u32 s_h[RADIX];
+    for (int i = threadIdx.x; i < RADIX; i += blockDim.x) s_h[i] = 0;
+    __syncthreads();
+    const u32 per = (g.tiles + gridDim.x - 1) / gridDim.x;
+    const u32 t_lo = blockIdx.x * per;
+    const u32 t_hi = (t_lo + per < g.tiles) ? t_lo + per : g.tiles;
+    u32 cur_chunk = chunk_of_tile(t_lo, g.tpc);
+    for (u32 t = t_lo; t < t_hi; ++t) {
+        const u32 c = chunk_of_tile(t, g.tpc);
+        if (c != cur_chunk) { hist_flush(s_h, hist, cur_chunk); cur_chunk = c; }
+        const u64 base = (u64)t * g.tile;
+        for (u32 l = threadIdx.x; l < g.tile; l += blockDim.x) {
+            const u64 i = base + l;
+            if (i < g.n) atomicAdd(&s_h[(u32)(keys[i] >> shift) & mask], 1u);
+        }
+    }
+    if (t_lo < t_hi) hist_flush(s_h, hist, cur_chunk);
+}
+
+// digit_base[c][d] = sum_{d'<d} total[d'] + sum_{c'<c} cnt[c'][d]; one workgroup of 256
+__global__ __launch_bounds__(256) void radix_scan_hist_kernel(const u32* __restrict__ hist, u32* __restrict__ base) {
     __shared__ u32 s_w[4];
     const int d = threadIdx.x, lane = d & 63, w = d >> 6;
-    const u32 c = ghist[blockIdx.x * RADIX + d];
+    u32 cnt[NCHUNK];
+    u32 c = 0;
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) { cnt[k] = hist[k * RADIX + d]; c += cnt[k]; }
     u32 incl = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -86,33 +158,99 @@ __global__ __launch_bounds__(256) void radix_scan_hist_kernel(const u32* __restr
     }
     if (lane == 63) s_w[w] = incl;
     __syncthreads();
-    u32 woff = 0;
-    for (int i = 0; i < w; ++i) woff += s_w[i];
-    gbase[blockIdx.x * RADIX + d] = woff + incl - c;
+    u32 run = incl - c;
+    for (int i = 0; i < w; ++i) run += s_w[i];
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) { base[k * RADIX + d] = run; run += cnt[k]; }
+}
+
+// ---- decoupled look-back with a window of LB_WINDOW predecessors in flight -------------------------
+// A granule only ever goes  not-ready -> AGG -> INCL  and both published forms stay valid for
+// whoever read them, so window entries loaded early never go stale in a harmful way.
+__device__ __forceinline__ u32 lookback_prefix(const u64* __restrict__ status, u32 tile, u32 first_tile, u32 digit,
+                                               u32 epoch, DeviceStatus* dstat) {
+    u32 prefix = 0;
+    int64_t t = (int64_t)tile - 1;
+    const int64_t t0 = (int64_t)first_tile;
+    while (t >= t0) {
+        u64 w[LB_WINDOW];
+#pragma unroll
+        for (int i = 0; i < LB_WINDOW; ++i) {
+            const int64_t ti = t - i;
+            w[i] = (ti >= t0) ? __hip_atomic_load(&status[(u64)ti * RADIX + digit], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+        bool done = false;
+#pragma unroll
+        for (int i = 0; i < LB_WINDOW; ++i) {
+            const int64_t ti = t - i;
+            if (!done && ti >= t0) {
+                u64 x = w[i];
+                u32 spins = 0;
+                while (!((u32)(x >> 34) == epoch && ((x >> 32) & 3u) != 0)) {
+                    ++spins;
+                    if ((spins & 1023u) == 0) {
+                        if (spins >= SPIN_LIMIT ||
+                            __hip_atomic_load(&dstat->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                            __hip_atomic_store(&dstat->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            return prefix;  // poisoned; the host reports SA_HIP_EINTERNAL
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    x = __hip_atomic_load(&status[(u64)ti * RADIX + digit], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                prefix += (u32)x;
+                if (((x >> 32) & 3u) == FLAG_INCL) done = true;
+            }
+        }
+        if (done) break;
+        t -= LB_WINDOW;
+    }
+    return prefix;
 }
 
 // ---- the pass -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(SORT_BLOCK) void radix_onesweep_kernel(SortPassArgs a) {
-    constexpr int WAVES = SORT_BLOCK / WAVE;
-    __shared__ __attribute__((aligned(16))) u64 s_keys[SORT_TILE];  // reused as u32 values afterwards
-    __shared__ u32 s_whist[WAVES * RADIX];
+// ABL: ablation mask for tools/sortbench.hip only (0 in the product): 1 = no look-back,
+// 4 = no values, 8 = stores not scattered (streaming copy), 16 = no next-pass histogram.
+template <int BLOCK, int ABL = 0>
+__global__ __launch_bounds__(BLOCK, 4) void radix_onesweep_kernel(SortPassArgs a) {
+    constexpr int WAVES = BLOCK / WAVE;
+    constexpr int TILE = BLOCK * SORT_ITEMS;
+    constexpr int WH = (WAVES * RADIX > NCHUNK * RADIX) ? WAVES * RADIX : NCHUNK * RADIX;
+    static_assert(BLOCK >= RADIX, "one thread per digit in the scan / look-back phase");
+    __shared__ __attribute__((aligned(16))) u64 s_keys[TILE];  // reused as u32 values afterwards
+    __shared__ u32 s_whist[WH];   // per-wave digit counters; later the (chunk, next digit) histogram
     __shared__ u32 s_dstart[RADIX];
     __shared__ u32 s_gdelta[RADIX];
-    __shared__ u32 s_wsum[WAVES];
-    __shared__ u32 s_tile;
-    __shared__ u32 s_abort;
+    __shared__ u32 s_wsum[RADIX / WAVE];
+    __shared__ u32 s_tile;   // global tile index, or 0xFFFFFFFF = nothing left / abort
+    __shared__ u32 s_chunk;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 n = a.g.n;
     if (tid == 0) {
-        s_tile = atomicAdd(a.ticket, 1u);
-        // a failed spin anywhere poisons the sort: later tiles drain instead of spinning again
-        s_abort = __hip_atomic_load(&a.dstat->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // One tile per workgroup.  Start at the chunk of this XCD; a chunk whose ticket has run past
+        // its tile count is exhausted, move on to the next (ONE atomic per attempt, no pre-check:
+        // every extra dependent round trip here delays the tile's first load by ~1-3 us).
+        u32 tile = 0xFFFFFFFFu, chunk = 0;
+        const u32 home = a.home_mode == 0 ? xcc_id() : (a.home_mode == 1 ? 0u : (blockIdx.x & 7u));
+        for (int k = 0; k < NCHUNK; ++k) {
+            const u32 c = (home + k) & (NCHUNK - 1);
+            const u32 first = c * a.g.tpc;
+            if (first >= a.g.tiles) continue;
+            const u32 cnt = (a.g.tiles - first) < a.g.tpc ? (a.g.tiles - first) : a.g.tpc;
+            const u32 t = atomicAdd(&a.ticket[c], 1u);
+            if (t < cnt) { tile = first + t; chunk = c; break; }
+        }
+        s_tile = tile;
+        s_chunk = chunk;
     }
-    for (int i = tid; i < WAVES * RADIX; i += SORT_BLOCK) s_whist[i] = 0;
+    for (int i = tid; i < WAVES * RADIX; i += BLOCK) s_whist[i] = 0;
     __syncthreads();
     const u32 tile = s_tile;
-    const u64 tile_base = (u64)tile * SORT_TILE;
-    if (tile_base >= a.n || s_abort != 0) return;  // block-uniform
+    if (tile == 0xFFFFFFFFu) return;  // block-uniform
+    const u32 chunk = s_chunk;
+    const u32 first_tile = chunk * a.g.tpc;
+    const u64 tile_base = (u64)tile * TILE;
 
     // 1. load (wave-striped): wave w owns records [w*64*ITEMS, (w+1)*64*ITEMS) of the tile
     u64 key[SORT_ITEMS];
@@ -121,17 +259,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void radix_onesweep_kernel(SortPassArgs
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; ++j) {
         const u64 p = wbase + (u64)j * WAVE;
-        key[j] = (p < a.n) ? a.keys_in[p] : ~0ull;
-    }
-    if (a.vals_in) {
-#pragma unroll
-        for (int j = 0; j < SORT_ITEMS; ++j) {
-            const u64 p = wbase + (u64)j * WAVE;
-            val[j] = (p < a.n) ? a.vals_in[p] : 0u;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < SORT_ITEMS; ++j) val[j] = (u32)(wbase + (u64)j * WAVE);
+        key[j] = (p < n) ? a.keys_in[p] : ~0ull;
     }
 
     // 2. per-wave stable ranking with ballot match masks
@@ -140,7 +268,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void radix_onesweep_kernel(SortPassArgs
     const u64 lt = lanemask_lt();
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; ++j) {
-        const bool valid = (wbase + (u64)j * WAVE) < a.n;
+        const bool valid = (wbase + (u64)j * WAVE) < n;
         const u32 d = (u32)(key[j] >> a.shift) & a.mask;
         u64 peers = __ballot(valid);
 #pragma unroll
@@ -156,12 +284,23 @@ __global__ __launch_bounds__(SORT_BLOCK) void radix_onesweep_kernel(SortPassArgs
         __builtin_amdgcn_wave_barrier();
         rank[j] = prior + below;
     }
+    // values are fetched only now: their latency hides behind the count / look-back phase and
+    // they do not occupy registers during ranking
+    if (a.vals_in) {
+#pragma unroll
+        for (int j = 0; j < SORT_ITEMS; ++j) {
+            const u64 p = wbase + (u64)j * WAVE;
+            val[j] = (p < n) ? a.vals_in[p] : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SORT_ITEMS; ++j) val[j] = (u32)(wbase + (u64)j * WAVE);
+    }
     __syncthreads();
 
-    // 3. tile digit counts -> publish aggregate -> exclusive scan over digits -> look-back
+    // 3. tile digit counts -> publish aggregate -> exclusive scan over digits
     u32 count = 0, excl = 0;
-    {
-        // SORT_BLOCK == RADIX: thread d owns digit d
+    if (tid < RADIX) {
         u32 c = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
@@ -171,7 +310,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void radix_onesweep_kernel(SortPassArgs
         }
         count = c;
         __hip_atomic_store(&a.status[(u64)tile * RADIX + tid],
-                           pack_status(a.epoch, tile == 0 ? FLAG_INCL : FLAG_AGG, count),
+                           pack_status(a.epoch, tile == first_tile ? FLAG_INCL : FLAG_AGG, count),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         u32 incl = c;
 #pragma unroll
@@ -183,82 +322,81 @@ __global__ __launch_bounds__(SORT_BLOCK) void radix_onesweep_kernel(SortPassArgs
         excl = incl - c;
     }
     __syncthreads();
-    {
+    if (tid < RADIX) {
         u32 woff = 0;
         for (int i = 0; i < wave; ++i) woff += s_wsum[i];
         excl += woff;
         s_dstart[tid] = excl;
-        u32 prefix = 0;
-        if (tile > 0) {
-            int64_t t = (int64_t)tile - 1;
-            bool dead = false;
-            while (true) {
-                u64 w;
-                u32 spins = 0;
-                while (true) {
-                    w = __hip_atomic_load(&a.status[(u64)t * RADIX + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((u32)(w >> 34) == a.epoch && ((w >> 32) & 3u) != 0) break;
-                    ++spins;
-                    if ((spins & 1023u) == 0) {
-                        if (spins >= SPIN_LIMIT ||
-                            __hip_atomic_load(&a.dstat->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                            __hip_atomic_store(&a.dstat->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            dead = true;
-                            break;
-                        }
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (dead) break;
-                prefix += (u32)w;
-                if (((w >> 32) & 3u) == FLAG_INCL || t == 0) break;
-                --t;
-            }
-            __hip_atomic_store(&a.status[(u64)tile * RADIX + tid], pack_status(a.epoch, FLAG_INCL, prefix + count),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        s_gdelta[tid] = a.digit_base[tid] + prefix - excl;
     }
     __syncthreads();
 
-    // 4. keys -> LDS at their tile-local sorted position -> coalesced global stores per digit run
+    // 4. keys -> LDS at their tile-local sorted position (needs only tile-local offsets; gives the
+    //    predecessor tiles time to publish before the look-back below)
     u32 pos[SORT_ITEMS];
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; ++j) {
-        const bool valid = (wbase + (u64)j * WAVE) < a.n;
+        const bool valid = (wbase + (u64)j * WAVE) < n;
         const u32 d = (u32)(key[j] >> a.shift) & a.mask;
         pos[j] = s_dstart[d] + s_whist[wave * RADIX + d] + rank[j];
         if (valid) s_keys[pos[j]] = key[j];
     }
+    __syncthreads();   // keys are in LDS; s_whist is free from here on
+
+    // 5. look-back: exclusive prefix of this tile's digits over the predecessor tiles of its chunk;
+    //    meanwhile the other lanes clear the (chunk, next digit) histogram that reuses s_whist
+    const bool has_next = (a.next_shift >= 0) && !(ABL & 16);
+    if (has_next) for (int i = tid; i < NCHUNK * RADIX; i += BLOCK) s_whist[i] = 0;
+    if (tid < RADIX) {
+        u32 prefix = 0;
+        if (tile > first_tile && !(ABL & 1)) {
+            prefix = lookback_prefix(a.status, tile, first_tile, (u32)tid, a.epoch, a.dstat);
+            __hip_atomic_store(&a.status[(u64)tile * RADIX + tid], pack_status(a.epoch, FLAG_INCL, prefix + count),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_gdelta[tid] = a.digit_base[chunk * RADIX + tid] + prefix - excl;
+    }
     __syncthreads();
-    const u32 tile_n = (u32)((a.n - tile_base) < (u64)SORT_TILE ? (a.n - tile_base) : (u64)SORT_TILE);
+
+    // 6. coalesced global stores per digit run (+ next pass's per-chunk histogram)
+    const u32 tile_n = (u32)((n - tile_base) < (u64)TILE ? (n - tile_base) : (u64)TILE);
     u32 gidx[SORT_ITEMS];
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; ++k) {
-        const u32 p = k * SORT_BLOCK + tid;
+        const u32 p = k * BLOCK + tid;
         if (p < tile_n) {
             const u64 kk = s_keys[p];
             const u32 d = (u32)(kk >> a.shift) & a.mask;
             gidx[k] = s_gdelta[d] + p;
+            if constexpr (ABL & 8) gidx[k] = (u32)tile_base + p;
             a.keys_out[gidx[k]] = kk;
+            if (has_next) {
+                const u32 dn = (u32)(kk >> a.next_shift) & a.next_mask;
+                const u32 cn = chunk_of_tile(gidx[k] >> a.g.tile_shift, a.g.tpc);
+                atomicAdd(&s_whist[cn * RADIX + dn], 1u);
+            }
         }
     }
     __syncthreads();
+    if (has_next) {
+        for (int i = tid; i < NCHUNK * RADIX; i += BLOCK) {
+            const u32 v = s_whist[i];
+            if (v) atomicAdd(&a.next_hist[i], v);
+        }
+    }
+    if constexpr (ABL & 4) return;
     u32* s_vals = reinterpret_cast<u32*>(s_keys);
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; ++j) {
-        const bool valid = (wbase + (u64)j * WAVE) < a.n;
+        const bool valid = (wbase + (u64)j * WAVE) < n;
         if (valid) s_vals[pos[j]] = val[j];
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; ++k) {
-        const u32 p = k * SORT_BLOCK + tid;
+        const u32 p = k * BLOCK + tid;
         if (p < tile_n) a.vals_out[gidx[k]] = s_vals[p];
     }
 }
-
-static_assert(SORT_BLOCK == RADIX, "one thread per digit in the scan / look-back phase");
 
 // ---- host driver ----------------------------------------------------------------------------------
 
@@ -307,21 +445,33 @@ struct EventTimer {
 
 struct RadixWorkspace {
     u64* status = nullptr;     // [max_tiles][RADIX]
-    u32* small = nullptr;      // tickets[16] | ghist[8*RADIX] | gbase[8*RADIX]
+    u32* small = nullptr;      // tickets[MAX_PASSES][NCHUNK] | hist[MAX_PASSES][NCHUNK][RADIX] | base[NCHUNK][RADIX]
     DeviceStatus* dstat = nullptr;
     u32 max_tiles = 0;
     u32 epoch = 0;
+    int block = 512;           // workgroup size of the pass kernel (tile = block * SORT_ITEMS)
     EventTimer timer;          // onesweep launches only
     u64 pass_records = 0;      // sum over passes of records moved
     u64 passes = 0;
 
+    int num_cus = 256;         // hipDeviceProp_t.multiProcessorCount
+    u32 tile() const { return (u32)block * SORT_ITEMS; }
+    // persistent workgroups: what one launch keeps resident (LDS-limited: 2 x 512 or 3 x 256 per CU)
+    u32 persistent_grid() const { return (u32)num_cus * (block == 512 ? 2u : 3u); }
     u32* tickets() const { return small; }
-    u32* ghist() const { return small + 16; }
-    u32* gbase() const { return small + 16 + 8 * RADIX; }
-    static size_t small_bytes() { return (16 + 16 * RADIX) * sizeof(u32); }
+    u32* hist(int pass) const { return small + MAX_PASSES * NCHUNK + (size_t)pass * NCHUNK * RADIX; }
+    u32* base() const { return small + MAX_PASSES * NCHUNK + (size_t)MAX_PASSES * NCHUNK * RADIX; }
+    // tickets + histograms (what a sort zeroes up front)
+    static size_t zero_bytes() { return (size_t)(MAX_PASSES * NCHUNK + MAX_PASSES * NCHUNK * RADIX) * sizeof(u32); }
+    static size_t small_bytes() { return zero_bytes() + (size_t)NCHUNK * RADIX * sizeof(u32); }
 
-    int init(u64 n_max) {
-        max_tiles = div_up(n_max ? n_max : 1, SORT_TILE);
+    int init(u64 n_max, int block_threads) {
+        block = block_threads;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            num_cus = prop.multiProcessorCount;
+        max_tiles = div_up(n_max ? n_max : 1, 256 * SORT_ITEMS);  // sized for the smaller tile
         SA_HIP_CHECK(hipMalloc(&status, (size_t)max_tiles * RADIX * sizeof(u64)));
         SA_HIP_CHECK(hipMemset(status, 0, (size_t)max_tiles * RADIX * sizeof(u64)));
         SA_HIP_CHECK(hipMalloc(&small, small_bytes()));
@@ -340,55 +490,86 @@ struct RadixWorkspace {
     void reset_stats() { timer.reset(); pass_records = 0; passes = 0; }
 };
 
+struct SortPlan {
+    int begin_bit, end_bit, npasses;
+    u32 last_mask;
+    SortGeom g;
+    int shift(int p) const { return begin_bit + RADIX_BITS * p; }
+    u32 mask(int p) const { return (p == npasses - 1) ? last_mask : (u32)(RADIX - 1); }
+};
+inline int make_plan(const RadixWorkspace& ws, u32 n, int begin_bit, int end_bit, SortPlan& p) {
+    p.begin_bit = begin_bit;
+    p.end_bit = end_bit;
+    p.npasses = (end_bit - begin_bit + RADIX_BITS - 1) / RADIX_BITS;
+    if (p.npasses > MAX_PASSES) return fail(SA_HIP_EINVAL, "radix sort: more than 8 passes");
+    const int last_bits = end_bit - begin_bit - RADIX_BITS * (p.npasses - 1);
+    p.last_mask = (1u << last_bits) - 1u;
+    p.g = make_geom(n, ws.tile());
+    if (p.g.tiles > ws.max_tiles) return fail(SA_HIP_EINVAL, "radix sort: workspace too small");
+    return 0;
+}
+
+// Zero tickets + histograms; a producer kernel may then fill ws.hist(0) for the plan's pass 0.
+inline int radix_prepare(RadixWorkspace& ws, hipStream_t stream) {
+    SA_HIP_CHECK(hipMemsetAsync(ws.small, 0, RadixWorkspace::zero_bytes(), stream));
+    return 0;
+}
+
 // Sort n records by key bits [begin_bit, end_bit), stable.  Buffers ping-pong A -> B -> A ...;
-// on return *keys_res / *vals_res point at the buffers holding the result.  vals iota: the
-// first pass generates value = position instead of reading valsA.
+// on return *keys_res / *vals_res point at the buffers holding the result.  iota_vals: the
+// first pass generates value = position instead of reading valsA.  hist_ready: the caller ran
+// radix_prepare() and a producer kernel already filled ws.hist(0) for exactly this plan.
 inline int radix_sort_pairs(RadixWorkspace& ws, hipStream_t stream, u64* keysA, u32* valsA, u64* keysB, u32* valsB,
-                            u32 n, int begin_bit, int end_bit, bool iota_vals, u64** keys_res, u32** vals_res) {
+                            u32 n, int begin_bit, int end_bit, bool iota_vals, bool hist_ready, u64** keys_res,
+                            u32** vals_res) {
     *keys_res = keysA;
     *vals_res = valsA;
     if (n == 0 || end_bit <= begin_bit) {
         if (iota_vals && n) return fail(SA_HIP_EINVAL, "radix_sort_pairs: iota with zero passes");
         return 0;
     }
-    const int npasses = (end_bit - begin_bit + RADIX_BITS - 1) / RADIX_BITS;
-    if (npasses > 8) return fail(SA_HIP_EINVAL, "radix_sort_pairs: more than 8 passes");
-    const int last_bits = end_bit - begin_bit - RADIX_BITS * (npasses - 1);
-    const u32 last_mask = (1u << last_bits) - 1u;
-    const u32 tiles = div_up(n, SORT_TILE);
-    if (tiles > ws.max_tiles) return fail(SA_HIP_EINVAL, "radix_sort_pairs: workspace too small");
-
-    SA_HIP_CHECK(hipMemsetAsync(ws.small, 0, RadixWorkspace::small_bytes(), stream));
-    u32 hgrid = div_up(n, 256 * 16);
-    if (hgrid > 2048) hgrid = 2048;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(hgrid), dim3(256), 0, stream, keysA, n, begin_bit, npasses, last_mask,
-                       ws.ghist());
-    hipLaunchKernelGGL(radix_scan_hist_kernel, dim3(npasses), dim3(256), 0, stream, ws.ghist(), ws.gbase());
+    SortPlan pl;
+    int rc = make_plan(ws, n, begin_bit, end_bit, pl);
+    if (rc) return rc;
+    if (!hist_ready) {
+        if ((rc = radix_prepare(ws, stream))) return rc;
+        u32 hgrid = pl.g.tiles < 2048u ? pl.g.tiles : 2048u;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(hgrid), dim3(256), 0, stream, keysA, pl.g, pl.shift(0), pl.mask(0),
+                           ws.hist(0));
+    }
 
     u64* kin = keysA; u32* vin = valsA; u64* kout = keysB; u32* vout = valsB;
-    for (int p = 0; p < npasses; ++p) {
+    for (int p = 0; p < pl.npasses; ++p) {
         if (++ws.epoch >= (1u << 30)) {  // epoch wrap: re-zero the granules once per 2^30 passes
             SA_HIP_CHECK(hipMemsetAsync(ws.status, 0, (size_t)ws.max_tiles * RADIX * sizeof(u64), stream));
             ws.epoch = 1;
         }
+        hipLaunchKernelGGL(radix_scan_hist_kernel, dim3(1), dim3(256), 0, stream, ws.hist(p), ws.base());
         SortPassArgs a;
         a.keys_in = kin;
         a.vals_in = (p == 0 && iota_vals) ? nullptr : vin;
         a.keys_out = kout;
         a.vals_out = vout;
-        a.n = n;
-        a.shift = begin_bit + RADIX_BITS * p;
-        a.mask = (p == npasses - 1) ? last_mask : (u32)(RADIX - 1);
-        a.digit_base = ws.gbase() + p * RADIX;
+        a.g = pl.g;
+        a.shift = pl.shift(p);
+        a.mask = pl.mask(p);
+        const bool last = (p == pl.npasses - 1);
+        a.next_shift = last ? -1 : pl.shift(p + 1);
+        a.next_mask = last ? 0u : pl.mask(p + 1);
+        a.digit_base = ws.base();
+        a.next_hist = last ? nullptr : ws.hist(p + 1);
         a.status = ws.status;
-        a.ticket = ws.tickets() + p;
+        a.ticket = ws.tickets() + p * NCHUNK;
         a.epoch = ws.epoch;
         a.dstat = ws.dstat;
-        int rc = ws.timer.start(stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(radix_onesweep_kernel, dim3(tiles), dim3(SORT_BLOCK), 0, stream, a);
-        rc = ws.timer.stop(stream);
-        if (rc) return rc;
+        a.home_mode = 0;
+        if ((rc = ws.timer.start(stream))) return rc;
+        const u32 grid = pl.g.tiles;   // one tile per workgroup
+        if (ws.block == 512)
+            hipLaunchKernelGGL((radix_onesweep_kernel<512, 0>), dim3(grid), dim3(512), 0, stream, a);
+        else
+            hipLaunchKernelGGL((radix_onesweep_kernel<256, 0>), dim3(grid), dim3(256), 0, stream, a);
+        if ((rc = ws.timer.stop(stream))) return rc;
         ws.pass_records += n;
         ws.passes += 1;
         u64* tk = kin; kin = kout; kout = tk;

@@ -17,6 +17,8 @@
 //   isa      u32[n]              rank of every suffix (allocated on the first doubling round)
 //   round pool (37 B x M0)       apos/aidx/gid lists, round keys + indices ping-pong, local flags
 #pragma once
+#include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -64,14 +66,28 @@ __global__ __launch_bounds__(256) void byte_hist_kernel(const u8* __restrict__ t
 // ---- initial keys: key[i] = codes of T[i..i+k0) packed MSB-first, b bits each ----------------------
 // One workgroup stages BLD_TILE + k0 text bytes as codes in LDS (16-byte global loads), every
 // thread then assembles the keys of 16 positions (stride 256 -> 8-byte coalesced stores).
+// While the keys are in registers the workgroup also accumulates the per-chunk histogram of the
+// first digit of the sort that follows (ghist != nullptr), which saves an 8-byte/record pre-pass
+// (later passes get their histograms from the pass before them, radix_sort.hpp).
 __global__ __launch_bounds__(BLD_BLOCK) void keygen_kernel(const u8* __restrict__ text, u64 n, CodeMap map, int b,
-                                                           int k0, u64* __restrict__ keys) {
+                                                           int k0, u64* __restrict__ keys, SortGeom g, int shift0,
+                                                           u32 mask0, u32* __restrict__ ghist) {
     __shared__ u16 s_map[256];
     __shared__ u16 s_codes[BLD_TILE + 64 + 16];
+    __shared__ u32 s_h[RADIX];
     s_map[threadIdx.x] = map.code[threadIdx.x];
+    s_h[threadIdx.x] = 0;
     const u64 ntiles = (n + BLD_TILE - 1) / BLD_TILE;
-    for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const u64 per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const u64 t_lo = (u64)blockIdx.x * per;
+    const u64 t_hi = (t_lo + per < ntiles) ? t_lo + per : ntiles;
+    u32 cur_chunk = chunk_of_tile((u32)((t_lo * BLD_TILE) >> g.tile_shift), g.tpc);
+    for (u64 tile = t_lo; tile < t_hi; ++tile) {
         const u64 base = tile * BLD_TILE;
+        if (ghist) {
+            const u32 c = chunk_of_tile((u32)(base >> g.tile_shift), g.tpc);
+            if (c != cur_chunk) { hist_flush(s_h, ghist, cur_chunk); cur_chunk = c; }
+        }
         __syncthreads();
         {   // body: 16 bytes per thread (text is padded by >= 16 readable bytes past n)
             uint4 x = make_uint4(0, 0, 0, 0);
@@ -101,9 +117,11 @@ __global__ __launch_bounds__(BLD_BLOCK) void keygen_kernel(const u8* __restrict_
                     key |= (u64)s_codes[l + j] << sh;
                 }
                 keys[p] = key;
+                if (ghist) atomicAdd(&s_h[(u32)(key >> shift0) & mask0], 1u);
             }
         }
     }
+    if (ghist && t_lo < t_hi) hist_flush(s_h, ghist, cur_chunk);
 }
 
 // ---- head / active flags + per-tile counts -------------------------------------------------------------
@@ -150,30 +168,65 @@ __global__ __launch_bounds__(BLD_BLOCK) void flags_kernel(const u64* __restrict_
     }
 }
 
-// exclusive scan of the per-tile {active, heads} pairs, single workgroup; totals[0..1] = sums
-__global__ __launch_bounds__(1024) void scan_counts_kernel(uint2* __restrict__ counts, u32 ntiles, u32* __restrict__ totals) {
-    __shared__ u32 s_a[1024], s_h[1024];
-    const u32 per = (ntiles + 1023) / 1024;
-    const u32 lo = threadIdx.x * per;
-    const u32 hi = (lo + per < ntiles) ? lo + per : ntiles;
-    u32 a = 0, h = 0;
-    for (u32 i = lo; i < hi; ++i) { a += counts[i].x; h += counts[i].y; }
-    s_a[threadIdx.x] = a; s_h[threadIdx.x] = h;
+// exclusive scan of the per-tile {active, heads} pairs in three coalesced steps:
+//   reduce 1024 tiles per workgroup -> scan the partials (one workgroup) -> scan inside each group.
+__device__ __forceinline__ uint2 block_excl_scan_1024(uint2 v, u32* s_a, u32* s_h, uint2* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 ia = v.x, ih = v.y;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 ta = __shfl_up(ia, o), th = __shfl_up(ih, o);
+        if (lane >= o) { ia += ta; ih += th; }
+    }
+    if (lane == 63) { s_a[wave] = ia; s_h[wave] = ih; }
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        u32 ta = 0, th = 0;
-        if ((int)threadIdx.x >= o) { ta = s_a[threadIdx.x - o]; th = s_h[threadIdx.x - o]; }
-        __syncthreads();
-        s_a[threadIdx.x] += ta; s_h[threadIdx.x] += th;
-        __syncthreads();
+    u32 oa = 0, oh = 0, ta = 0, th = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) { oa += s_a[w]; oh += s_h[w]; }
+        ta += s_a[w]; th += s_h[w];
     }
-    u32 ea = s_a[threadIdx.x] - a, eh = s_h[threadIdx.x] - h;
+    __syncthreads();
+    if (total) *total = make_uint2(ta, th);
+    return make_uint2(oa + ia - v.x, oh + ih - v.y);
+}
+
+__global__ __launch_bounds__(1024) void counts_reduce_kernel(const uint2* __restrict__ counts, u32 ntiles,
+                                                             uint2* __restrict__ partial) {
+    __shared__ u32 s_a[16], s_h[16];
+    const u32 i = blockIdx.x * 1024 + threadIdx.x;
+    uint2 v = (i < ntiles) ? counts[i] : make_uint2(0, 0);
+    uint2 tot;
+    (void)block_excl_scan_1024(v, s_a, s_h, &tot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// nparts <= 1024 * PER; one workgroup; partial[] becomes exclusive, totals[0..1] = sums
+__global__ __launch_bounds__(1024) void counts_scan_partials_kernel(uint2* __restrict__ partial, u32 nparts,
+                                                                    u32* __restrict__ totals) {
+    __shared__ u32 s_a[16], s_h[16];
+    const u32 per = (nparts + 1023) / 1024;
+    const u32 lo = threadIdx.x * per;
+    const u32 hi = (lo + per < nparts) ? lo + per : nparts;
+    uint2 v = make_uint2(0, 0);
+    for (u32 i = lo; i < hi; ++i) { v.x += partial[i].x; v.y += partial[i].y; }
+    uint2 tot;
+    uint2 e = block_excl_scan_1024(v, s_a, s_h, &tot);
     for (u32 i = lo; i < hi; ++i) {
-        const uint2 c = counts[i];
-        counts[i] = make_uint2(ea, eh);
-        ea += c.x; eh += c.y;
+        const uint2 c = partial[i];
+        partial[i] = e;
+        e.x += c.x; e.y += c.y;
     }
-    if (threadIdx.x == 1023) { totals[0] = s_a[1023]; totals[1] = s_h[1023]; }
+    if (threadIdx.x == 0) { totals[0] = tot.x; totals[1] = tot.y; }
+}
+
+__global__ __launch_bounds__(1024) void counts_apply_kernel(uint2* __restrict__ counts, u32 ntiles,
+                                                            const uint2* __restrict__ partial) {
+    __shared__ u32 s_a[16], s_h[16];
+    const u32 i = blockIdx.x * 1024 + threadIdx.x;
+    uint2 v = (i < ntiles) ? counts[i] : make_uint2(0, 0);
+    const uint2 e = block_excl_scan_1024(v, s_a, s_h, nullptr);
+    const uint2 base = partial[blockIdx.x];
+    if (i < ntiles) counts[i] = make_uint2(base.x + e.x, base.y + e.y);
 }
 
 // ---- compaction of the active elements ---------------------------------------------------------------
@@ -399,6 +452,35 @@ struct Builder {
     sa_hip_build_stats stats;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int chunk_rounds_before_doubling = 2;
+    int initial_chars_override = 0;   // SA_HIP_INITIAL_CHARS: 0 = heuristic
+    bool fuse_hist = true;            // SA_HIP_FUSE_HIST: digit histograms inside keygen
+    DevBuf partial;
+
+    // Characters in the initial key.  Enough that, for an i.i.d. text with this byte
+    // distribution, about 2 % of the suffixes still share their key (collision probability
+    // per character c2 = sum p_i^2), then rounded up to fill whole 8-bit sort passes.
+    int choose_initial_chars(int b, u32 L) const {
+        const int kmax = 64 / b;
+        int k = kmax;
+        if (initial_chars_override > 0) {
+            k = initial_chars_override < kmax ? initial_chars_override : kmax;
+        } else {
+            double c2 = 0.0;
+            for (int c = 0; c < 256; ++c) { const double pr = (double)freq[c] / (double)n; c2 += pr * pr; }
+            if (c2 < 0.999999) {
+                const double need = std::log(0.02 / (double)n) / std::log(c2);
+                int kk = (int)std::ceil(need);
+                if (kk < 1) kk = 1;
+                if (kk < kmax) {
+                    const int passes = (kk * b + RADIX_BITS - 1) / RADIX_BITS;
+                    kk = (passes * RADIX_BITS) / b;
+                    k = kk < kmax ? kk : kmax;
+                }
+            }
+        }
+        if (L && (u32)k > L) k = (int)L;
+        return k < 1 ? 1 : k;
+    }
 
     int init(u64 nmax, hipStream_t s) {
         stream = s;
@@ -407,7 +489,12 @@ struct Builder {
         int rc;
         if ((rc = text.ensure(cap + TEXT_PAD + 16))) return rc;
         if ((rc = small.ensure(4096))) return rc;
-        if ((rc = radix.init(cap))) return rc;
+        int sort_block = 512;
+        if (const char* e = getenv("SA_HIP_SORT_BLOCK")) sort_block = (atoi(e) == 256) ? 256 : 512;
+        if (const char* e = getenv("SA_HIP_INITIAL_CHARS")) initial_chars_override = atoi(e);
+        if (const char* e = getenv("SA_HIP_CHUNK_ROUNDS")) chunk_rounds_before_doubling = atoi(e);
+        if (const char* e = getenv("SA_HIP_FUSE_HIST")) fuse_hist = atoi(e) != 0;
+        if ((rc = radix.init(cap, sort_block))) return rc;
         SA_HIP_CHECK(hipEventCreate(&ev_begin));
         SA_HIP_CHECK(hipEventCreate(&ev_end));
         memset(&stats, 0, sizeof stats);
@@ -427,7 +514,7 @@ struct Builder {
     }
     void destroy() {
         DevBuf* all[] = {&text, &keys0, &keys1, &vals0, &vals1, &flags, &counts, &small, &isa, &apos0, &apos1, &aidx,
-                         &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own};
+                         &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial};
         for (DevBuf* b : all) b->release();
         radix.destroy();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
@@ -476,7 +563,12 @@ struct Builder {
         const u32 tiles = div_up(cnt, BLD_TILE);
         hipLaunchKernelGGL(flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, keys, cnt, lf_out, counts.as<uint2>(),
                            apos, sidx, sa, flags.as<u8>());
-        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, counts.as<uint2>(), tiles, totals_dev());
+        const u32 parts = div_up(tiles, 1024);
+        int rc = partial.ensure((size_t)parts * sizeof(uint2) + 64);
+        if (rc) return rc;
+        hipLaunchKernelGGL(counts_reduce_kernel, dim3(parts), dim3(1024), 0, stream, counts.as<uint2>(), tiles, partial.as<uint2>());
+        hipLaunchKernelGGL(counts_scan_partials_kernel, dim3(1), dim3(1024), 0, stream, partial.as<uint2>(), parts, totals_dev());
+        hipLaunchKernelGGL(counts_apply_kernel, dim3(parts), dim3(1024), 0, stream, counts.as<uint2>(), tiles, partial.as<uint2>());
         return read_totals(totals_host);
     }
 
@@ -516,17 +608,20 @@ struct Builder {
             SA_HIP_CHECK(hipMemsetAsync(flags.p, 1, 1, stream));
             return finish_stats();
         }
-        int k0 = 64 / b;
-        if (L && (u32)k0 > L) k0 = (int)L;
+        const int k0 = choose_initial_chars(b, L);
         stats.initial_chars = (u32)k0;
         const u32 n32 = (u32)n;
 
-        // initial keys + sort #0
+        // initial keys (+ fused digit histograms) + sort #0
+        SortPlan pl;
+        if ((rc = make_plan(radix, n32, 64 - b * k0, 64, pl))) return rc;
+        if (fuse_hist) { if ((rc = radix_prepare(radix, stream))) return rc; }
         hipLaunchKernelGGL(keygen_kernel, dim3(stream_grid(n, BLD_TILE)), dim3(BLD_BLOCK), 0, stream, text.as<u8>(), n, map, b,
-                           k0, keys0.as<u64>());
+                           k0, keys0.as<u64>(), pl.g, pl.shift(0), pl.mask(0),
+                           fuse_hist ? radix.hist(0) : (u32*)nullptr);
         u64* kres; u32* vres;
         if ((rc = radix_sort_pairs(radix, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(), n32,
-                                   64 - b * k0, 64, true, &kres, &vres))) return rc;
+                                   64 - b * k0, 64, true, fuse_hist, &kres, &vres))) return rc;
         sa = vres;
 
         // head flags, active counts
@@ -594,7 +689,7 @@ struct Builder {
             SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
             const int end_bit = use_chunk ? 64 : (gb + rb);
             if ((rc = radix_sort_pairs(radix, stream, rkeys0.as<u64>(), ridx0.as<u32>(), rkeys1.as<u64>(), ridx1.as<u32>(), M,
-                                       begin_bit, end_bit, false, &kres, &vres))) return rc;
+                                       begin_bit, end_bit, false, false, &kres, &vres))) return rc;
             // write back, new heads, counts
             if ((rc = flags_and_counts(kres, M, lf.as<u8>(), apos_cur, vres, tot))) return rc;
             if ((rc = check_device_status())) return rc;

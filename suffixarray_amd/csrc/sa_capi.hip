@@ -371,7 +371,7 @@ int sa_hip_sort_pairs(uint64_t* keys, uint32_t* values, uint64_t n, int begin_bi
     SA_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     RadixWorkspace ws;
     DevBuf k0, k1, v0, v1;
-    rc = ws.init(n);
+    rc = ws.init(n, 256);
     if (!rc) rc = k0.ensure(n * 8);
     if (!rc) rc = k1.ensure(n * 8);
     if (!rc) rc = v0.ensure(n * 4);
@@ -381,7 +381,7 @@ int sa_hip_sort_pairs(uint64_t* keys, uint32_t* values, uint64_t n, int begin_bi
         SA_HIP_CHECK(hipMemcpyAsync(k0.p, keys, n * 8, hipMemcpyHostToDevice, stream));
         if (values) SA_HIP_CHECK(hipMemcpyAsync(v0.p, values, n * 4, hipMemcpyHostToDevice, stream));
         int r = radix_sort_pairs(ws, stream, k0.as<u64>(), v0.as<u32>(), k1.as<u64>(), v1.as<u32>(), (u32)n, begin_bit,
-                                 end_bit, values == nullptr, &kr, &vr);
+                                 end_bit, values == nullptr, false, &kr, &vr);
         if (r) return r;
         SA_HIP_CHECK(hipMemcpyAsync(keys, kr, n * 8, hipMemcpyDeviceToHost, stream));
         if (values) SA_HIP_CHECK(hipMemcpyAsync(values, vr, n * 4, hipMemcpyDeviceToHost, stream));

@@ -1,0 +1,100 @@
+// sortbench.hip -- ablation micro-benchmark of ONE radix pass (diagnostic build, not shipped).
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -o /tmp/sortbench tools/sortbench.hip && /tmp/sortbench [log2n]
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../suffixarray_amd/csrc/radix_sort.hpp"
+using namespace sa;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+__global__ void fill_keys(u64* k, u32* v, u64 n, int bits) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        u64 x = i * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+        x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29;
+        k[i] = x << (64 - bits);
+        v[i] = (u32)i;
+    }
+}
+__global__ void copy_kernel(const uint4* __restrict__ a, uint4* __restrict__ b, u64 n16) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) b[i] = a[i];
+}
+
+template <int BLOCK, int ABL>
+float run_pass(RadixWorkspace& ws, hipStream_t st, u64* k0, u32* v0, u64* k1, u32* v1, u32 n, int shift, int reps, int home_mode = 0) {
+    SortGeom g = make_geom(n, BLOCK * SORT_ITEMS);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9f;
+    for (int r = 0; r < reps; ++r) {
+        CK(hipMemsetAsync(ws.small, 0, RadixWorkspace::zero_bytes(), st));
+        u32 hgrid = g.tiles < 2048u ? g.tiles : 2048u;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(hgrid), dim3(256), 0, st, k0, g, shift, 255u, ws.hist(0));
+        hipLaunchKernelGGL(radix_scan_hist_kernel, dim3(1), dim3(256), 0, st, ws.hist(0), ws.base());
+        SortPassArgs a;
+        a.keys_in = k0; a.vals_in = v0; a.keys_out = k1; a.vals_out = v1; a.g = g; a.shift = shift; a.mask = 255u;
+        a.next_shift = shift + 8; a.next_mask = 255u; a.next_hist = ws.hist(1);
+        a.digit_base = ws.base(); a.status = ws.status; a.ticket = ws.tickets(); a.epoch = ++ws.epoch; a.dstat = ws.dstat; a.home_mode = home_mode;
+        CK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL((radix_onesweep_kernel<BLOCK, ABL>), dim3(g.tiles), dim3(BLOCK), 0, st, a);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    return best;
+}
+
+int main(int argc, char** argv) {
+    const int lg = argc > 1 ? atoi(argv[1]) : 28;
+    const u32 n = lg > 64 ? (u32)atoll(argv[1]) : (1u << lg);   // small arg = log2, large arg = record count
+    hipStream_t st; CK(hipStreamCreate(&st));
+    u64 *k0, *k1; u32 *v0, *v1;
+    CK(hipMalloc(&k0, (size_t)n * 8)); CK(hipMalloc(&k1, (size_t)n * 8));
+    CK(hipMalloc(&v0, (size_t)n * 4)); CK(hipMalloc(&v1, (size_t)n * 4));
+    RadixWorkspace ws;
+    if (ws.init(n, 256)) { printf("ws init failed\n"); return 1; }
+    fill_keys<<<2048, 256, 0, st>>>(k0, v0, n, 40);
+    CK(hipStreamSynchronize(st));
+    const double gb = (double)n * 24.0 / 1e9;
+    // streaming copy baseline: same bytes (12 B/record in, 12 out)
+    {
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        float best = 1e9f;
+        for (int r = 0; r < 5; ++r) {
+            CK(hipEventRecord(e0, st));
+            copy_kernel<<<4096, 256, 0, st>>>((const uint4*)k0, (uint4*)k1, (u64)n * 8 / 16);
+            copy_kernel<<<4096, 256, 0, st>>>((const uint4*)v0, (uint4*)v1, (u64)n * 4 / 16);
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+        }
+        printf("n=2^%d  copy(12B/rec)            %8.3f ms  %7.1f GB/s\n", lg, best, gb / best * 1e3);
+    }
+    const int shift = 24;   // a uniformly distributed digit
+#define RUN(B, A, name) { float ms = run_pass<B, A>(ws, st, k0, v0, k1, v1, n, shift, 4); \
+        printf("block %d abl %2d %-28s %8.3f ms  %7.1f GB/s\n", B, A, name, ms, gb / ms * 1e3); fflush(stdout); }
+    RUN(256, 0, "full")
+    RUN(256, 1, "no lookback")
+    RUN(256, 16, "no next-hist")
+    RUN(256, 17, "no lookback, no next-hist")
+    RUN(256, 8, "linear stores")
+    RUN(512, 0, "full")
+    RUN(512, 1, "no lookback")
+    RUN(512, 16, "no next-hist")
+    RUN(512, 17, "no lookback, no next-hist")
+    RUN(512, 8, "linear stores")
+    RUN(512, 4, "no values")
+#define RUNH(B, A, H, name) { float ms = run_pass<B, A>(ws, st, k0, v0, k1, v1, n, shift, 4, H); \
+        printf("block %d abl %2d home %d %-22s %8.3f ms  %7.1f GB/s\n", B, A, H, name, ms, gb / ms * 1e3); fflush(stdout); }
+    RUNH(512, 17, 1, "no lb/nh, home=0")
+    RUNH(512, 17, 2, "no lb/nh, home=bid&7")
+    RUNH(512, 0, 1, "full, home=0")
+    RUNH(512, 0, 2, "full, home=bid&7")
+    RUNH(256, 17, 1, "no lb/nh, home=0")
+    RUNH(256, 17, 2, "no lb/nh, home=bid&7")
+    RUNH(256, 0, 1, "full, home=0")
+    DeviceStatus ds; CK(hipMemcpy(&ds, ws.dstat, sizeof ds, hipMemcpyDeviceToHost));
+    printf("device error flag: %u\n", ds.error);
+    return 0;
+}
