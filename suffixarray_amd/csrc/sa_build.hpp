@@ -412,6 +412,46 @@ __global__ void iota_kernel(u32* __restrict__ out, u64 n) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (u32)i;
 }
 
+// ---- query acceleration structures (used by sa_query.hpp) -------------------------------------------
+// keys[j] = packed first k0 characters of suffix sa[j] (for indexes adopted with sa_hip_index_load)
+__global__ __launch_bounds__(256) void gather_keys_kernel(const u8* __restrict__ text, u64 n, CodeMap map, int b, int k0,
+                                                          const u32* __restrict__ sa, u64* __restrict__ keys) {
+    __shared__ u16 s_map[256];
+    s_map[threadIdx.x] = map.code[threadIdx.x];
+    __syncthreads();
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const u64 start = sa[j];
+        u64 key = 0;
+        int sh = 64;
+        for (int i = 0; i < k0; ++i) {
+            const u64 p = start + i;
+            sh -= b;
+            const u64 c = (p < n) ? (u64)s_map[text[p]] : 0ull;
+            key |= c << sh;
+        }
+        keys[j] = key;
+    }
+}
+
+// dir[bkt] = first slot whose key has top-dbits >= bkt, by binary search; dir[2^dbits] = n
+__global__ __launch_bounds__(256) void dir_build_kernel(const u64* __restrict__ keys, u64 n, int dbits, u32* __restrict__ dir) {
+    const u64 nb = (1ull << dbits) + 1;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 bkt = (u64)blockIdx.x * blockDim.x + threadIdx.x; bkt < nb; bkt += stride) {
+        u64 lo = 0, hi = n;
+        if (bkt == nb - 1) lo = n;
+        else {
+            const u64 bound = bkt << (64 - dbits);
+            while (lo < hi) {
+                const u64 mid = (lo + hi) >> 1;
+                if (keys[mid] < bound) lo = mid + 1; else hi = mid;
+            }
+        }
+        dir[bkt] = (u32)lo;
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------
 
 struct DevBuf {
@@ -455,6 +495,11 @@ struct Builder {
     int initial_chars_override = 0;   // SA_HIP_INITIAL_CHARS: 0 = heuristic
     bool fuse_hist = true;            // SA_HIP_FUSE_HIST: digit histograms inside keygen
     DevBuf partial;
+    // query acceleration (sa_query.hpp): sorted packed keys K + bucket directory
+    const u64* qkeys = nullptr;   // points into keys0/keys1 (build) or keys0 (load)
+    DevBuf qdir;
+    CodeMap qmap;
+    int q_b = 0, q_k0 = 0, q_dbits = 0;
 
     // Characters in the initial key.  Enough that, for an i.i.d. text with this byte
     // distribution, about 2 % of the suffixes still share their key (collision probability
@@ -514,7 +559,7 @@ struct Builder {
     }
     void destroy() {
         DevBuf* all[] = {&text, &keys0, &keys1, &vals0, &vals1, &flags, &counts, &small, &isa, &apos0, &apos1, &aidx,
-                         &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial};
+                         &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir};
         for (DevBuf* b : all) b->release();
         radix.destroy();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
@@ -585,6 +630,37 @@ struct Builder {
         return 0;
     }
 
+    // Bucket directory over the top q_dbits bits of the sorted keys (qkeys must be set).
+    int build_directory() {
+        if (!qkeys || n < 2) { qkeys = nullptr; return 0; }
+        int lg = 0;
+        while ((1ull << lg) < n) ++lg;
+        int d = lg - 9;
+        if (d < 8) d = 8;
+        if (d > 22) d = 22;
+        q_dbits = d;
+        const u64 nb = (1ull << d) + 1;
+        int rc = qdir.ensure((size_t)nb * 4);
+        if (rc) return rc;
+        hipLaunchKernelGGL(dir_build_kernel, dim3(stream_grid(nb, 256)), dim3(256), 0, stream, qkeys, n, d, qdir.as<u32>());
+        SA_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+
+    // Query structures for an adopted (text, SA): packed keys gathered from the text.
+    int prepare_query_from_sa(const CodeMap& map, int b, u32 L) {
+        qkeys = nullptr;
+        if (n < 2) return 0;
+        const int k0 = choose_initial_chars(b, L);
+        int rc = keys0.ensure((size_t)n * 8);
+        if (rc) return rc;
+        hipLaunchKernelGGL(gather_keys_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, stream, text.as<u8>(), n, map, b, k0,
+                           (const u32*)sa, keys0.as<u64>());
+        qkeys = keys0.as<u64>();
+        qmap = map; q_b = b; q_k0 = k0;
+        return build_directory();
+    }
+
     // The device build.  Text already resident in text.p[0..n_).
     int build(u64 n_, u32 L) {
         int rc;
@@ -602,6 +678,7 @@ struct Builder {
         stats.sigma = sigma;
         stats.bits_per_symbol = (u32)b;
         sa = vals0.as<u32>();
+        qkeys = nullptr;
         if (n == 0) return finish_stats();
         if (n == 1) {
             SA_HIP_CHECK(hipMemsetAsync(sa, 0, 4, stream));
@@ -623,6 +700,8 @@ struct Builder {
         if ((rc = radix_sort_pairs(radix, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(), n32,
                                    64 - b * k0, 64, true, fuse_hist, &kres, &vres))) return rc;
         sa = vres;
+        qkeys = kres;   // sorted packed keys: kept for the query path (sa_query.hpp)
+        qmap = map; q_b = b; q_k0 = k0;
 
         // head flags, active counts
         u32 tot[2];
@@ -711,6 +790,7 @@ struct Builder {
             if (stats.rounds > 200) return fail(SA_HIP_EINTERNAL, "refinement did not converge");
         }
         stats.final_depth = (u32)(h > 0xFFFFFFFFull ? 0xFFFFFFFFull : h);
+        if ((rc = build_directory())) return rc;
         return finish_stats();
     }
 

@@ -42,11 +42,14 @@ int launch_query(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q
     a.offsets = off_dev;
     a.q = Q;
     a.out = out_dev;
+    a.keys = idx->b.qkeys;
+    a.dir = idx->b.qdir.as<u32>();
+    a.b = idx->b.q_b; a.k0 = idx->b.q_k0; a.dbits = idx->b.q_dbits;
     SA_HIP_CHECK(hipEventRecord(idx->q_begin, idx->stream));
     if (Q) {
         u64 g = (Q + 255) / 256;
         if (g > 256u * 16u) g = 256u * 16u;
-        hipLaunchKernelGGL(query_kernel, dim3((u32)g), dim3(256), 0, idx->stream, a);
+        hipLaunchKernelGGL(query_kernel, dim3((u32)g), dim3(256), 0, idx->stream, a, idx->b.qmap);
     }
     SA_HIP_CHECK(hipEventRecord(idx->q_end, idx->stream));
     SA_HIP_CHECK(hipGetLastError());
@@ -153,6 +156,8 @@ static int load_common(sa_hip_index* idx, const void* T, const void* SA, uint64_
     if ((rc = b.prepare_text(n, map, sigma, bits))) return rc;
     b.sa = b.sa_own.as<u32>();
     b.max_suffix_length = L;
+    if ((rc = b.prepare_query_from_sa(map, bits, L))) return rc;
+    SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
     idx->has_index = true;
     return 0;
 }

@@ -7,12 +7,22 @@
 // Result conventions (engine.c:896-898, 916-917): {lb, ub-1}; lb == n -> {UINT32_MAX,UINT32_MAX}.
 // The reference's uint32 wrap of `mid - 1` at mid == 0 (engine.c:891,908) is NOT reproduced.
 //
-// v1 kernel: one lane per query.  The lower-bound descent remembers the tightest strictly
-// greater slot, so the upper-bound search starts inside [lb, hi_strict) -- for a miss it
-// costs one extra probe instead of a second full descent.  Pattern bytes are fetched once into
-// registers as big-endian 64-bit words (<= 32 bytes; longer patterns fall back to memory).
+// The reference probes SA[mid] and then the text at SA[mid]: two dependent random HBM reads per
+// step, ~2*log2(n) steps.  Here one lane per query works on three HBM-resident structures:
+//   K    u64[n]  the packed first-k0-characters key of every SA slot (the build's sorted key array,
+//                kept instead of discarded; b bits per character after alphabet compaction).  A
+//                search step is ONE aligned 8-byte load, no indirection, and the last three steps
+//                of a descent fall into one 64-byte sector.
+//   dir  u32[2^dbits + 1]  bucket directory over the top dbits of K (first slot of every bucket):
+//                one load replaces the top ~20 levels of the descent (it stays resident in the
+//                L2 / Infinity Cache across the batch).
+//   SA,T only for the final disambiguation beyond k0 characters, inside the (usually 0..2 slot)
+//                range that K leaves.
+// The lower-bound descent remembers the tightest strictly-greater slot, so the upper bound
+// starts inside [lb, hi_strict).
 #pragma once
 #include "common.hpp"
+#include "sa_build.hpp"
 
 namespace sa {
 
@@ -75,9 +85,16 @@ struct QueryArgs {
     const u64* offsets;     // [q + 1]
     u64 q;
     sa_hip_pair_u32* out;
+    // acceleration structures (keys == nullptr: plain SA/text descent)
+    const u64* keys;        // K
+    const u32* dir;         // bucket directory, 2^dbits + 1 entries
+    int b, k0, dbits;
 };
 
-__global__ __launch_bounds__(256) void query_kernel(QueryArgs a) {
+__global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
+    __shared__ u16 s_map[256];
+    s_map[threadIdx.x] = map.code[threadIdx.x];
+    __syncthreads();
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 qi = (u64)blockIdx.x * blockDim.x + threadIdx.x; qi < a.q; qi += stride) {
         const u64 o = a.offsets[qi];
@@ -89,26 +106,70 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) qw[j] = pattern_word(q, c, j);
 
-        // lower bound: first slot whose suffix is >= pattern
-        u64 lo = 0, hi = a.n, hi_strict = a.n;
-        while (lo < hi) {
-            const u64 mid = (lo + hi) >> 1;
-            const int r = cmp_suffix<4>(a.text, a.n, a.sa[mid], qw, q, c);
-            if (r < 0) lo = mid + 1;
-            else { hi = mid; if (r > 0) hi_strict = mid; }
+        // ---- phase 1: narrow to the slots whose first P characters equal the pattern's -----------
+        u64 lo = 0, hi = a.n;      // lb and ub both lie in [lo, hi]
+        bool exact = false;        // the K range IS the answer (whole pattern packed)
+        if (a.keys) {
+            int P = 0;
+            u64 key_lo = 0;
+            int sh = 64;
+            const int pmax = (c < (u32)a.k0) ? (int)c : a.k0;
+            for (; P < pmax; ++P) {
+                const u32 code = s_map[q[P]];
+                if (code == 0) break;   // byte absent from the text: nothing matches past here
+                sh -= a.b;
+                key_lo |= (u64)code << sh;
+            }
+            if (P > 0) {
+                const u64 key_hi = key_lo | ((sh > 0) ? ((1ull << sh) - 1ull) : 0ull);
+                const int ds = 64 - a.dbits;
+                const u32 bl = (u32)(key_lo >> ds), bh = (u32)(key_hi >> ds);
+                u64 l = a.dir[bl], h = a.dir[bl + 1];
+                u64 h_strict = (bh == bl) ? h : a.dir[bh + 1];   // first slot known to be > key_hi
+                const u64 h2_lo = (bh == bl) ? 0 : a.dir[bh];
+                // first slot with K >= key_lo
+                while (l < h) {
+                    const u64 mid = (l + h) >> 1;
+                    const u64 k = a.keys[mid];
+                    if (k < key_lo) l = mid + 1;
+                    else { h = mid; if (k > key_hi) h_strict = mid; }
+                }
+                lo = l;
+                // first slot with K > key_hi, inside [max(lo, dir[bh]), h_strict]
+                u64 l2 = (bh == bl) ? lo : (h2_lo > lo ? h2_lo : lo);
+                u64 h2 = h_strict;
+                while (l2 < h2) {
+                    const u64 mid = (l2 + h2) >> 1;
+                    if (a.keys[mid] <= key_hi) l2 = mid + 1; else h2 = mid;
+                }
+                hi = l2;
+                exact = ((u32)P == c);
+            }
         }
-        const u64 lb = lo;
-        // upper bound: first slot whose suffix is > pattern, inside [lb, hi_strict]
-        hi = hi_strict;
-        while (lo < hi) {
-            const u64 mid = (lo + hi) >> 1;
-            const int r = cmp_suffix<4>(a.text, a.n, a.sa[mid], qw, q, c);
-            if (r <= 0) lo = mid + 1;
-            else hi = mid;
+
+        // ---- phase 2: text comparisons inside [lo, hi) ---------------------------------------------
+        u64 lb = lo, ub = hi;
+        if (!exact) {
+            u64 l = lo, h = hi, h_strict = hi;
+            while (l < h) {
+                const u64 mid = (l + h) >> 1;
+                const int r = cmp_suffix<4>(a.text, a.n, a.sa[mid], qw, q, c);
+                if (r < 0) l = mid + 1;
+                else { h = mid; if (r > 0) h_strict = mid; }
+            }
+            lb = l;
+            h = h_strict;
+            while (l < h) {
+                const u64 mid = (l + h) >> 1;
+                const int r = cmp_suffix<4>(a.text, a.n, a.sa[mid], qw, q, c);
+                if (r <= 0) l = mid + 1;
+                else h = mid;
+            }
+            ub = l;
         }
         sa_hip_pair_u32 res;
         if (lb == a.n) { res.first = 0xFFFFFFFFu; res.second = 0xFFFFFFFFu; }
-        else { res.first = (u32)lb; res.second = (u32)(lo - 1); }
+        else { res.first = (u32)lb; res.second = (u32)(ub - 1); }
         a.out[qi] = res;
     }
 }
