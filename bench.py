@@ -31,7 +31,8 @@ def cpu_baseline(text, q_buf, q_off, sample_n, sample_q):
     bounded prefix of the same text, all host cores; falls back to the oracle port."""
     from oracle.oracle import Oracle, Ref
     t = np.ascontiguousarray(text[:sample_n])
-    cores = os.cpu_count() or 1
+    cores = max(1, len(os.sched_getaffinity(0)))   # host cores this process may use
+    threads = int(os.environ.get("OMP_NUM_THREADS", cores))
     os.environ.setdefault("OMP_DYNAMIC", "false")
     out = {}
     orc = Oracle()
@@ -39,11 +40,11 @@ def cpu_baseline(text, q_buf, q_off, sample_n, sample_q):
         ref = Ref()
         sa64 = np.zeros(t.size, dtype=np.int64)  # first-touched
         t0 = time.perf_counter()
-        rc = ref.libsais64_into(t, sa64, 0)
+        rc = ref.libsais64_into(t, sa64, threads)
         dt = time.perf_counter() - t0
         assert rc == 0
-        out.update(kind="reference", value=t.size / dt, unit="chars/s", cores=cores,
-                   sample=f"libsais64_omp(threads=0 -> {cores}) on the first {t.size:,} chars of the same text, 1 run: {dt:.2f} s")
+        out.update(kind="reference", value=t.size / dt, unit="chars/s", cores=threads,
+                   sample=f"libsais64_omp(threads={threads}; {cores} cores visible, {os.cpu_count()} in the machine) on the first {t.size:,} chars of the same text, 1 run: {dt:.2f} s")
         sa = sa64.astype(np.uint32)
     else:
         t0 = time.perf_counter()
@@ -54,7 +55,7 @@ def cpu_baseline(text, q_buf, q_off, sample_n, sample_q):
     # query baseline: oracle restatement of get_substring_positions, OpenMP over the batch
     nq = min(sample_q, q_off.size - 1)
     t0 = time.perf_counter()
-    orc.query_batch(t, sa, 0xFFFFFFFF, (q_buf[:int(q_off[nq])], q_off[:nq + 1]), threads=0)
+    orc.query_batch(t, sa, 0xFFFFFFFF, (q_buf[:int(q_off[nq])], q_off[:nq + 1]), threads=threads)
     dq = time.perf_counter() - t0
     out["queries_per_s"] = nq / dq
     out["query_sample"] = f"{nq:,} of the same 16-byte patterns over the sample SA, {orc.threads_used} threads: {dq:.2f} s"

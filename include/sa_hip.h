@@ -138,6 +138,12 @@ int sa_hip_index_get_sa_range(sa_hip_index* idx, uint64_t first, uint64_t count,
 
 int sa_hip_index_sync(sa_hip_index* idx);
 
+/* On-device check that the index's SA is the suffix array of its text (truncated indexes: that
+ * it is a permutation ordered by the first max_suffix_length bytes, ties in text order).
+ * *violations = 0 means verified.  O(n) device work, 4n bytes of device scratch; the O(n)
+ * "sufcheck" that makes bit-exactness testable at n = 1e9 without a CPU oracle run. */
+int sa_hip_index_verify(sa_hip_index* idx, uint64_t* violations);
+
 /* ---- instrumentation ---------------------------------------------------------------------- */
 
 /* Per-build statistics of the last build on this handle (roofline accounting). */

@@ -24,7 +24,7 @@ EXPORTS = [
     "sa_hip_index_max_suffix_length", "sa_hip_index_text_dev", "sa_hip_index_sa_dev",
     "sa_hip_index_stream", "sa_hip_index_get_sa_u32", "sa_hip_index_get_sa_i64",
     "sa_hip_index_get_freq", "sa_hip_query_batch", "sa_hip_query_batch_device",
-    "sa_hip_index_get_sa_range", "sa_hip_index_sync", "sa_hip_index_build_stats",
+    "sa_hip_index_get_sa_range", "sa_hip_index_sync", "sa_hip_index_verify", "sa_hip_index_build_stats",
     "sa_hip_index_query_stats", "sa_hip_sort_pairs", "sa_hip_synth_uniform27", "sa_hip_last_error", "sa_hip_version",
 ]
 
@@ -124,6 +124,8 @@ def lib():
     L.sa_hip_index_get_sa_range.argtypes = [vp, u64, u64, vp]
     L.sa_hip_index_sync.restype = C.c_int
     L.sa_hip_index_sync.argtypes = [vp]
+    L.sa_hip_index_verify.restype = C.c_int
+    L.sa_hip_index_verify.argtypes = [vp, C.POINTER(u64)]
     L.sa_hip_index_build_stats.restype = C.c_int
     L.sa_hip_index_build_stats.argtypes = [vp, C.POINTER(BuildStats)]
     L.sa_hip_index_query_stats.restype = C.c_int
@@ -246,6 +248,12 @@ class DeviceIndex:
 
     def sync(self):
         check(self._lib.sa_hip_index_sync(self._h))
+
+    def verify(self):
+        """Number of violations of the suffix-array property found on the device (0 = verified)."""
+        v = C.c_uint64(0)
+        check(self._lib.sa_hip_index_verify(self._h, C.byref(v)))
+        return int(v.value)
 
     def build_stats(self):
         st = BuildStats()

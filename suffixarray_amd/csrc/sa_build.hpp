@@ -412,6 +412,65 @@ __global__ void iota_kernel(u32* __restrict__ out, u64 n) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (u32)i;
 }
 
+// ---- on-device verification (sufcheck) ----------------------------------------------
+// SA is the suffix array of T  <=>  it is a permutation of [0,n) and for every adjacent pair
+// (a, b) = (SA[j-1], SA[j]):  T[a] < T[b], or T[a] == T[b] and suffix a+1 sorts before suffix b+1
+// (the empty suffix first) -- by induction over the suffix order the second test may use the
+// ranks ISA[a+1] < ISA[b+1] of the array under test.  O(n) work, 4n bytes of scratch.
+__global__ void verify_scatter_kernel(const u32* __restrict__ sa, u64 n, u32* __restrict__ isa, u64* __restrict__ bad) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const u32 v = sa[j];
+        if (v >= n) atomicAdd((unsigned long long*)bad, 1ull);
+        else isa[v] = (u32)j;
+    }
+}
+__global__ void verify_order_kernel(const u8* __restrict__ text, const u32* __restrict__ sa, const u32* __restrict__ isa,
+                                    u64 n, u64* __restrict__ bad) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u64 local = 0;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const u32 b = sa[j];
+        if (b >= n) continue;                       // counted by the scatter kernel
+        if (isa[b] != (u32)j) { ++local; continue; }   // duplicate value: not a permutation
+        if (j == 0) continue;
+        const u32 a = sa[j - 1];
+        if (a >= n) continue;
+        const u8 ca = text[a], cb = text[b];
+        if (ca > cb) ++local;
+        else if (ca == cb) {
+            if ((u64)a + 1 == n) { /* empty suffix first: fine */ }
+            else if ((u64)b + 1 == n) ++local;
+            else if (isa[a + 1] >= isa[b + 1]) ++local;
+        }
+    }
+    if (local) atomicAdd((unsigned long long*)bad, (unsigned long long)local);
+}
+// truncated order: adjacent suffixes compare <= on their first L bytes (a suffix that ends sorts
+// first), ties in text order
+__global__ void verify_truncated_kernel(const u8* __restrict__ text, const u32* __restrict__ sa, const u32* __restrict__ isa,
+                                        u64 n, u32 L, u64* __restrict__ bad) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u64 local = 0;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const u32 b = sa[j];
+        if (b >= n) continue;
+        if (isa[b] != (u32)j) { ++local; continue; }
+        if (j == 0) continue;
+        const u32 a = sa[j - 1];
+        if (a >= n) continue;
+        int r = 0;
+        for (u32 i = 0; i < L && r == 0; ++i) {
+            const u64 pa = (u64)a + i, pb = (u64)b + i;
+            const int xa = pa < n ? (int)text[pa] : -1, xb = pb < n ? (int)text[pb] : -1;
+            if (xa != xb) r = xa < xb ? -1 : 1;
+            else if (xa < 0) break;
+        }
+        if (r > 0 || (r == 0 && a > b)) ++local;
+    }
+    if (local) atomicAdd((unsigned long long*)bad, (unsigned long long)local);
+}
+
 // ---- query acceleration structures (used by sa_query.hpp) -------------------------------------------
 // keys[j] = packed first k0 characters of suffix sa[j] (for indexes adopted with sa_hip_index_load)
 __global__ __launch_bounds__(256) void gather_keys_kernel(const u8* __restrict__ text, u64 n, CodeMap map, int b, int k0,
@@ -659,6 +718,27 @@ struct Builder {
         qkeys = keys0.as<u64>();
         qmap = map; q_b = b; q_k0 = k0;
         return build_directory();
+    }
+
+    // Number of violations of the suffix-array property (0 = verified).
+    int verify(u64* violations) {
+        *violations = 0;
+        if (n == 0) return 0;
+        int rc = isa.ensure((size_t)n * 4);
+        if (rc) return rc;
+        u64* bad = reinterpret_cast<u64*>(small.as<u8>() + 3072);
+        SA_HIP_CHECK(hipMemsetAsync(bad, 0, 8, stream));
+        SA_HIP_CHECK(hipMemsetAsync(isa.p, 0xFF, (size_t)n * 4, stream));
+        const u32 g = stream_grid(n, 1024);
+        hipLaunchKernelGGL(verify_scatter_kernel, dim3(g), dim3(256), 0, stream, (const u32*)sa, n, isa.as<u32>(), bad);
+        if (max_suffix_length == 0)
+            hipLaunchKernelGGL(verify_order_kernel, dim3(g), dim3(256), 0, stream, text.as<u8>(), (const u32*)sa, isa.as<u32>(), n, bad);
+        else
+            hipLaunchKernelGGL(verify_truncated_kernel, dim3(g), dim3(256), 0, stream, text.as<u8>(), (const u32*)sa, isa.as<u32>(), n,
+                               max_suffix_length, bad);
+        SA_HIP_CHECK(hipMemcpyAsync(violations, bad, 8, hipMemcpyDeviceToHost, stream));
+        SA_HIP_CHECK(hipStreamSynchronize(stream));
+        return 0;
     }
 
     // The device build.  Text already resident in text.p[0..n_).

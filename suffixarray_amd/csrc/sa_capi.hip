@@ -188,6 +188,14 @@ int sa_hip_index_sync(sa_hip_index* idx) {
     return 0;
 }
 
+int sa_hip_index_verify(sa_hip_index* idx, uint64_t* violations) {
+    if (!idx || !idx->has_index || !violations) return fail(SA_HIP_EINVAL, "sa_hip_index_verify: no index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    return idx->b.verify(violations);
+}
+
 int sa_hip_index_get_sa_u32(sa_hip_index* idx, uint32_t* out_host) {
     if (!idx || !idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_u32: no index");
     if (!out_host && idx->b.n) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_u32: NULL output");
