@@ -33,6 +33,19 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+def build_cython(force=False, verbose=False):
+    """The Cython binding (suffix_array.pyx -> suffixarray_amd/suffix_array.*.so), in-tree."""
+    import glob
+    pyx = os.path.join(_HERE, "suffix_array.pyx")
+    built = glob.glob(os.path.join(_HERE, "suffix_array.*.so"))
+    if built and not force and all(os.path.getmtime(b) >= max(os.path.getmtime(pyx), os.path.getmtime(LIB)) for b in built):
+        return built[0]
+    cmd = [sys.executable, os.path.join(_HERE, "setup_cython.py"), "build_ext", "--inplace"]
+    subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)
+    return glob.glob(os.path.join(_HERE, "suffix_array.*.so"))[0]
+
+
 if __name__ == "__main__":
     build_lib(force="--force" in sys.argv, verbose=True)
     print(LIB)
+    print(build_cython(force="--force" in sys.argv, verbose=True))

@@ -32,8 +32,9 @@ def ref():
 @pytest.fixture(scope="session")
 def capi():
     """The C ABI; building is part of the contract (hipcc cross-compiles without a GPU)."""
-    from suffixarray_amd.build import build_lib
+    from suffixarray_amd.build import build_lib, build_cython
     build_lib()
+    build_cython()
     from suffixarray_amd import _capi
     _capi.lib()
     return _capi

@@ -116,3 +116,21 @@ def test_python_api_csv(gpu, tmp_path):
     assert s.query_records("acme, inc")[0] == {"id": "2", "company_name": "Acme, Inc.", "country": "US"}
     assert s.query_records("company_name") == []   # header row is not indexed
     s.close()
+
+
+def test_cython_api_matches_python_mirror(gpu, tmp_path):
+    from suffixarray_amd.suffix_array import SuffixArray as CySuffixArray
+    from suffixarray_amd import SuffixArray
+    docs = ["The quick brown fox jumps over the lazy dog",
+            "I am going to the store to buy some milk",
+            "Uhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhh"]
+    a, b = CySuffixArray(documents=docs, max_suffix_length=32), SuffixArray(documents=docs, max_suffix_length=32)
+    for q in ("the quick brown fox", "the", "MILK", "zzz", "", "uhh", "o"):
+        assert a.query_records(q) == b.query_records(q), q
+    assert a.query_records("the quick brown fox") == [docs[0]]
+    assert np.array_equal(a.query_ranges(["the", "fox", "zzz"]), b.query_ranges(["the", "fox", "zzz"]))
+    p = tmp_path / "c.csv"
+    p.write_text('id,company_name,country\n1,Netflix,US\n2,"Acme, Inc.",US\n3,netflix studios,US\n')
+    c = CySuffixArray(csv_file=str(p), search_column="company_name", max_suffix_length=32)
+    assert sorted(r["id"] for r in c.query_records("netflix")) == ["1", "3"]
+    a.close(); b.close(); c.close()

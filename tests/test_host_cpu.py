@@ -85,3 +85,13 @@ def test_csv_ingest(tmp_path):
     assert data[col.row_file_offsets[1]:col.row_file_offsets[2]] == b'2,"Acme, Inc.",US\n'
     with pytest.raises(ValueError):
         extract_column(str(p), "nope")
+
+
+def test_cython_binding_builds_and_fails_loudly_without_gpu(capi):
+    from suffixarray_amd.suffix_array import SuffixArray
+    if capi.lib().sa_hip_device_count() >= 1:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(RuntimeError):
+        SuffixArray(documents=["a", "b"], max_suffix_length=8)
+    with pytest.raises(ValueError):
+        SuffixArray(documents=["a"], csv_file="x.csv")
