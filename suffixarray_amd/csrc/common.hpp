@@ -52,6 +52,18 @@ __device__ __forceinline__ u64 lanemask_lt() {
     return (1ull << (threadIdx.x & 63)) - 1ull;
 }
 
+// Workgroup barrier that first drains this wave's outstanding LDS operations explicitly.
+// hipcc (ROCm 7.2, gfx950) was observed to emit a bare `s_barrier` -- no `s_waitcnt lgkmcnt(0)` --
+// on a loop path where the only pending LDS operations were no-return atomics (`ds_add_u32`)
+// issued in the previous iteration: another wave then read the counter before the add landed and
+// a whole wave-instruction of increments was lost (found on 6.7e7-record sorts: a per-chunk
+// histogram short by exactly 64).  Every barrier that follows LDS atomics uses this form; inline
+// asm is invisible to the waitcnt-insertion pass, so the wait cannot be dropped.
+__device__ __forceinline__ void sync_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // Device error word shared by every kernel that can spin (decoupled look-back).
 // 0 = ok; anything else = a bounded spin expired, results are invalid.
 struct DeviceStatus {

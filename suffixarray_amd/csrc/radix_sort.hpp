@@ -110,7 +110,7 @@ struct SortPassArgs {
 // hist layout: [chunk][RADIX].  Every workgroup owns a contiguous range of tiles so that it crosses
 // a chunk boundary at most a few times (LDS histogram flushed at each crossing).
 __device__ __forceinline__ void hist_flush(u32* s_h, u32* hist, u32 chunk) {
-    __syncthreads();
+    sync_lds();   // LDS atomics of the tile loop must have landed (see sync_lds)
     for (int d = threadIdx.x; d < RADIX; d += blockDim.x) {
         const u32 v = s_h[d];
         if (v) {
@@ -118,7 +118,7 @@ __device__ __forceinline__ void hist_flush(u32* s_h, u32* hist, u32 chunk) {
             s_h[d] = 0;
         }
     }
-    __syncthreads();
+    sync_lds();
 }
 
 __global__ __launch_bounds__(256) void radix_hist_kernel(const u64* __restrict__ keys, SortGeom g, int shift,
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(BLOCK, 4) void radix_onesweep_kernel(SortPassArgs a
             }
         }
     }
-    __syncthreads();
+    sync_lds();   // LDS atomics above (see sync_lds)
     if (has_next) {
         for (int i = tid; i < NCHUNK * RADIX; i += BLOCK) {
             const u32 v = s_whist[i];
@@ -453,6 +453,10 @@ struct RadixWorkspace {
     EventTimer timer;          // onesweep launches only
     u64 pass_records = 0;      // sum over passes of records moved
     u64 passes = 0;
+    // debugging aid: called after every pass with the pass's output (SA_HIP_DEBUG_ROUNDS)
+    void (*debug_hook)(void* ctx, int pass, int npasses, int shift, u32 mask, const u64* kin, const u32* vin,
+                       const u64* keys, const u32* vals, u32 n) = nullptr;
+    void* debug_ctx = nullptr;
 
     int num_cus = 256;         // hipDeviceProp_t.multiProcessorCount
     u32 tile() const { return (u32)block * SORT_ITEMS; }
@@ -572,6 +576,7 @@ inline int radix_sort_pairs(RadixWorkspace& ws, hipStream_t stream, u64* keysA, 
         if ((rc = ws.timer.stop(stream))) return rc;
         ws.pass_records += n;
         ws.passes += 1;
+        if (ws.debug_hook) ws.debug_hook(ws.debug_ctx, p, pl.npasses, a.shift, a.mask, kin, a.vals_in, kout, vout, n);
         u64* tk = kin; kin = kout; kout = tk;
         u32* tv = vin; vin = vout; vout = tv;
     }

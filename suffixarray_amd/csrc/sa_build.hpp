@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void byte_hist_kernel(const u8* __restrict__ t
     if (blockIdx.x == 0) {
         for (u64 i = nvec * 16 + threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_h[text[i]], 1u);
     }
-    __syncthreads();
+    sync_lds();   // LDS atomics above (see sync_lds)
     const u32 c = s_h[threadIdx.x];
     if (c) atomicAdd((unsigned long long*)&hist[threadIdx.x], (unsigned long long)c);
 }
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(BLD_BLOCK) void keygen_kernel(const u8* __restrict_
             const u32 c = chunk_of_tile((u32)(base >> g.tile_shift), g.tpc);
             if (c != cur_chunk) { hist_flush(s_h, ghist, cur_chunk); cur_chunk = c; }
         }
-        __syncthreads();
+        sync_lds();   // previous tile's LDS atomics + code reads (see sync_lds)
         {   // body: 16 bytes per thread (text is padded by >= 16 readable bytes past n)
             uint4 x = make_uint4(0, 0, 0, 0);
             if (base + (u64)threadIdx.x * 16 < n) x = *reinterpret_cast<const uint4*>(text + base + (u64)threadIdx.x * 16);
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(BLD_BLOCK) void keygen_kernel(const u8* __restrict_
             const u64 p = base + BLD_TILE + threadIdx.x;
             s_codes[BLD_TILE + threadIdx.x] = (p < n) ? s_map[text[p]] : (u16)0;
         }
-        __syncthreads();
+        sync_lds();
 #pragma unroll 4
         for (int it = 0; it < BLD_ITEMS; ++it) {
             const u32 l = it * BLD_BLOCK + threadIdx.x;
@@ -471,6 +471,19 @@ __global__ void verify_truncated_kernel(const u8* __restrict__ text, const u32* 
     if (local) atomicAdd((unsigned long long*)bad, (unsigned long long)local);
 }
 
+// ---- debugging aid (SA_HIP_DEBUG_ROUNDS=1): duplicates in a list of suffix indices ------------------
+// mark[v] = 1 + slot of the first occurrence; dups[0] = count, dups[1 + 2k], dups[2 + 2k] = the two slots
+__global__ void dbg_dup_kernel(const u32* __restrict__ idx, u64 m, u32* __restrict__ mark, u64* __restrict__ dups) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const u32 old = atomicCAS(&mark[idx[j]], 0u, (u32)j + 1u);
+        if (old != 0) {
+            const u64 k = atomicAdd((unsigned long long*)dups, 1ull);
+            if (k < 24) { dups[1 + 2 * k] = old - 1; dups[2 + 2 * k] = j; }
+        }
+    }
+}
+
 // ---- query acceleration structures (used by sa_query.hpp) -------------------------------------------
 // keys[j] = packed first k0 characters of suffix sa[j] (for indexes adopted with sa_hip_index_load)
 __global__ __launch_bounds__(256) void gather_keys_kernel(const u8* __restrict__ text, u64 n, CodeMap map, int b, int k0,
@@ -553,7 +566,9 @@ struct Builder {
     int chunk_rounds_before_doubling = 2;
     int initial_chars_override = 0;   // SA_HIP_INITIAL_CHARS: 0 = heuristic
     bool fuse_hist = true;            // SA_HIP_FUSE_HIST: digit histograms inside keygen
-    DevBuf partial;
+    DevBuf partial, dbg;
+    bool debug_rounds = false;
+    bool dbg_failed = false;
     // query acceleration (sa_query.hpp): sorted packed keys K + bucket directory
     const u64* qkeys = nullptr;   // points into keys0/keys1 (build) or keys0 (load)
     DevBuf qdir;
@@ -598,6 +613,8 @@ struct Builder {
         if (const char* e = getenv("SA_HIP_INITIAL_CHARS")) initial_chars_override = atoi(e);
         if (const char* e = getenv("SA_HIP_CHUNK_ROUNDS")) chunk_rounds_before_doubling = atoi(e);
         if (const char* e = getenv("SA_HIP_FUSE_HIST")) fuse_hist = atoi(e) != 0;
+        if (const char* e = getenv("SA_HIP_DEBUG_ROUNDS")) debug_rounds = atoi(e) != 0;
+        if (debug_rounds) { radix.debug_hook = &Builder::sort_debug_hook; radix.debug_ctx = this; }
         if ((rc = radix.init(cap, sort_block))) return rc;
         SA_HIP_CHECK(hipEventCreate(&ev_begin));
         SA_HIP_CHECK(hipEventCreate(&ev_end));
@@ -618,7 +635,7 @@ struct Builder {
     }
     void destroy() {
         DevBuf* all[] = {&text, &keys0, &keys1, &vals0, &vals1, &flags, &counts, &small, &isa, &apos0, &apos1, &aidx,
-                         &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir};
+                         &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir, &dbg};
         for (DevBuf* b : all) b->release();
         radix.destroy();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
@@ -687,6 +704,46 @@ struct Builder {
         hipLaunchKernelGGL(scatter_ranks_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, lf_in, cnt, posmap, idx,
                            carry.as<u32>(), isa.as<u32>());
         return 0;
+    }
+
+    static void sort_debug_hook(void* ctx, int pass, int npasses, int shift, u32 mask, const u64* kin, const u32* vin,
+                                const u64* keys, const u32* vals, u32 cnt) {
+        Builder* b = static_cast<Builder*>(ctx);
+        if (b->dbg.ensure((size_t)b->n * 4 + 16)) return;
+        u64* dd = reinterpret_cast<u64*>(b->small.as<u8>() + 3072);
+        u64 dups[49];
+        (void)hipMemsetAsync(b->dbg.p, 0, (size_t)b->n * 4, b->stream);
+        (void)hipMemsetAsync(dd, 0, sizeof dups, b->stream);
+        hipLaunchKernelGGL(dbg_dup_kernel, dim3(stream_grid(cnt, 1024)), dim3(256), 0, b->stream, vals, (u64)cnt, b->dbg.as<u32>(), dd);
+        (void)hipMemcpyAsync(dups, dd, sizeof dups, hipMemcpyDeviceToHost, b->stream);
+        (void)hipStreamSynchronize(b->stream);
+        if (dups[0] && !b->dbg_failed && getenv("SA_HIP_DUMP")) {
+            // dump input and output of the failing pass for offline analysis
+            std::vector<u64> hk(cnt); std::vector<u32> hv(cnt);
+            const void* srcs[4] = {kin, vin, keys, vals};
+            const char* names[4] = {"/tmp/sa_pass_kin.bin", "/tmp/sa_pass_vin.bin", "/tmp/sa_pass_kout.bin", "/tmp/sa_pass_vout.bin"};
+            for (int q = 0; q < 4; ++q) {
+                const bool is_key = (q == 0 || q == 2);
+                (void)hipMemcpy(is_key ? (void*)hk.data() : (void*)hv.data(), srcs[q], (size_t)cnt * (is_key ? 8 : 4), hipMemcpyDeviceToHost);
+                FILE* f = fopen(names[q], "wb");
+                if (f) { fwrite(is_key ? (void*)hk.data() : (void*)hv.data(), is_key ? 8 : 4, cnt, f); fclose(f); }
+            }
+            {   // the radix workspace's small block: tickets | hist[pass][chunk][256] | base[chunk][256]
+                std::vector<u32> hs(RadixWorkspace::small_bytes() / 4);
+                (void)hipMemcpy(hs.data(), b->radix.small, RadixWorkspace::small_bytes(), hipMemcpyDeviceToHost);
+                FILE* g = fopen("/tmp/sa_pass_small.bin", "wb");
+                if (g) { fwrite(hs.data(), 4, hs.size(), g); fclose(g); }
+            }
+            FILE* f = fopen("/tmp/sa_pass_meta.txt", "w");
+            if (f) { fprintf(f, "%u %d %u %d %d\n", cnt, shift, mask, pass, npasses); fclose(f); }
+        }
+        if (dups[0]) {
+            b->dbg_failed = true;   // keep the dump of this round's sort input
+            fprintf(stderr, "[sa_hip]   sort pass %d/%d over %u records: %llu duplicate values; slot pairs:", pass, npasses, cnt, (unsigned long long)dups[0]);
+            for (u64 k = 0; k < dups[0] && k < 24; ++k) fprintf(stderr, " (%llu,%llu)", (unsigned long long)dups[1 + 2 * k], (unsigned long long)dups[2 + 2 * k]);
+            fprintf(stderr, "\n");
+        }
+        (void)keys;
     }
 
     // Bucket directory over the top q_dbits bits of the sorted keys (qkeys must be set).
@@ -847,6 +904,15 @@ struct Builder {
             // sort the active records; aidx is the value array
             SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
             const int end_bit = use_chunk ? 64 : (gb + rb);
+            if (debug_rounds && getenv("SA_HIP_DUMP") && atoi(getenv("SA_HIP_DUMP")) == 2 && !dbg_failed) {
+                std::vector<u64> hk(M); std::vector<u32> hv(M);
+                SA_HIP_CHECK(hipMemcpyAsync(hk.data(), rkeys0.p, (size_t)M * 8, hipMemcpyDeviceToHost, stream));
+                SA_HIP_CHECK(hipMemcpyAsync(hv.data(), ridx0.p, (size_t)M * 4, hipMemcpyDeviceToHost, stream));
+                SA_HIP_CHECK(hipStreamSynchronize(stream));
+                FILE* f = fopen("/tmp/sa_dump_keys.bin", "wb"); if (f) { fwrite(hk.data(), 8, M, f); fclose(f); }
+                f = fopen("/tmp/sa_dump_vals.bin", "wb"); if (f) { fwrite(hv.data(), 4, M, f); fclose(f); }
+                f = fopen("/tmp/sa_dump_meta.txt", "w"); if (f) { fprintf(f, "%u %d %d %u\n", M, begin_bit, end_bit, stats.rounds); fclose(f); }
+            }
             if ((rc = radix_sort_pairs(radix, stream, rkeys0.as<u64>(), ridx0.as<u32>(), rkeys1.as<u64>(), ridx1.as<u32>(), M,
                                        begin_bit, end_bit, false, false, &kres, &vres))) return rc;
             // write back, new heads, counts
@@ -854,6 +920,24 @@ struct Builder {
             if ((rc = check_device_status())) return rc;
             if (have_isa) {
                 if ((rc = scatter_ranks(lf.as<u8>(), M, apos_cur, vres))) return rc;
+            }
+            if (debug_rounds) {
+                u64 dups_sa = 0, dups_act = 0;
+                if ((rc = dbg.ensure((size_t)n * 4 + 16))) return rc;
+                u64* dd = reinterpret_cast<u64*>(small.as<u8>() + 3072);
+                SA_HIP_CHECK(hipMemsetAsync(dbg.p, 0, (size_t)n * 4, stream));
+                SA_HIP_CHECK(hipMemsetAsync(dd, 0, 49 * 8, stream));
+                hipLaunchKernelGGL(dbg_dup_kernel, dim3(stream_grid(n, 1024)), dim3(256), 0, stream, (const u32*)sa, n, dbg.as<u32>(), dd);
+                SA_HIP_CHECK(hipMemcpyAsync(&dups_sa, dd, 8, hipMemcpyDeviceToHost, stream));
+                SA_HIP_CHECK(hipStreamSynchronize(stream));
+                SA_HIP_CHECK(hipMemsetAsync(dbg.p, 0, (size_t)n * 4, stream));
+                SA_HIP_CHECK(hipMemsetAsync(dd, 0, 49 * 8, stream));
+                hipLaunchKernelGGL(dbg_dup_kernel, dim3(stream_grid(M, 1024)), dim3(256), 0, stream, (const u32*)vres, (u64)M, dbg.as<u32>(), dd);
+                SA_HIP_CHECK(hipMemcpyAsync(&dups_act, dd, 8, hipMemcpyDeviceToHost, stream));
+                SA_HIP_CHECK(hipStreamSynchronize(stream));
+                fprintf(stderr, "[sa_hip] round %u %s h=%llu M=%u G=%u -> M'=%u G'=%u passes=%d dupSA=%llu dupActive=%llu\n", stats.rounds,
+                        use_chunk ? "chunk" : "dbl", (unsigned long long)h, M, G, tot[0], tot[1], (end_bit - begin_bit + 7) / 8,
+                        (unsigned long long)dups_sa, (unsigned long long)dups_act);
             }
             stats.active_total += M;
             ++stats.rounds;
@@ -867,7 +951,7 @@ struct Builder {
             }
             M = M_next;
             G = tot[1];
-            if (stats.rounds > 200) return fail(SA_HIP_EINTERNAL, "refinement did not converge");
+            if (stats.rounds > (debug_rounds ? 40u : 200u)) return fail(SA_HIP_EINTERNAL, "refinement did not converge");
         }
         stats.final_depth = (u32)(h > 0xFFFFFFFFull ? 0xFFFFFFFFull : h);
         if ((rc = build_directory())) return rc;

@@ -384,7 +384,9 @@ int sa_hip_sort_pairs(uint64_t* keys, uint32_t* values, uint64_t n, int begin_bi
     SA_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     RadixWorkspace ws;
     DevBuf k0, k1, v0, v1;
-    rc = ws.init(n, 256);
+    int sort_block = 512;
+    if (const char* e = getenv("SA_HIP_SORT_BLOCK")) sort_block = (atoi(e) == 256) ? 256 : 512;
+    rc = ws.init(n, sort_block);
     if (!rc) rc = k0.ensure(n * 8);
     if (!rc) rc = k1.ensure(n * 8);
     if (!rc) rc = v0.ensure(n * 4);

@@ -99,3 +99,17 @@ def test_config3_n1e9_properties(gpu, oracle):
         nxt = s + 1 if s >= f else f
         if nxt < n:
             assert bytes(t[sa[nxt]:sa[nxt] + m]) > p
+
+
+def test_long_repeats_67m_many_doubling_rounds(gpu):
+    """A 1 MiB random block repeated 64 times: ~24 refinement rounds over 6.7e7 active records each.
+    Regression for a lost-LDS-atomic race (bare s_barrier after ds_add on a loop path, see
+    common.hpp sync_lds) that corrupted one per-chunk histogram in about one sort out of twenty."""
+    rng = np.random.default_rng(1)
+    t = np.tile(rng.integers(97, 123, 1 << 20, dtype=np.uint8), 64)
+    with gpu.DeviceIndex(t.size, 0) as idx:
+        for _ in range(2):
+            idx.build(t)
+            st = idx.build_stats()
+            assert st["doubling_rounds"] >= 20, st
+            assert idx.verify() == 0, st
