@@ -26,12 +26,43 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12  # MI355X HBM3E peak, B/s (MI355X_MICROARCH.md)
 
 
+def usable_cpus():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = max(1, len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pd = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = max(1, min(n, q // pd))
+        except Exception:
+            pass
+    return n
+
+
+def pmc_traffic(n, launches_per_step):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc run
+    (profiles/pmc_onesweep.json; PMC passes cannot run inside this process).  Only reported for
+    the workload it was measured on."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "pmc_onesweep.json")))
+    except Exception:
+        return None
+    if n != 1_000_000_000 or launches_per_step != 13:
+        return None
+    return j["traffic_bytes_per_launch"]
+
+
 def cpu_baseline(text, q_buf, q_off, sample_n, sample_q):
     """Reference libsais64_omp (oracle/_ref, compiled from the reference's own sources) on a
     bounded prefix of the same text, all host cores; falls back to the oracle port."""
     from oracle.oracle import Oracle, Ref
     t = np.ascontiguousarray(text[:sample_n])
-    cores = max(1, len(os.sched_getaffinity(0)))   # host cores this process may use
+    cores = usable_cpus()
     threads = int(os.environ.get("OMP_NUM_THREADS", cores))
     os.environ.setdefault("OMP_DYNAMIC", "false")
     out = {}
@@ -189,7 +220,9 @@ def main():
             "build_stats": {k: last[k] for k in ("sigma", "bits_per_symbol", "initial_chars", "rounds", "chunk_rounds",
                                                  "doubling_rounds", "final_depth", "radix_passes", "active_total")},
             "roofline": {"bound": "hbm", "kernel": "radix_onesweep_kernel", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                         "traffic": pmc_traffic(N, radix_launches // max(steps, 1)),
+                         "traffic_note": "bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE on this workload, profiles/pmc_onesweep.json",
                          "launches": radix_launches, "avg_launch_ms": pass_ms, "bytes_per_launch": bytes_per_launch},
             "roofline_query": {"bound": "hbm", "kernel": "query_kernel", "achieved": q_achieved / 1e9, "peak": HBM_PEAK / 1e9,
                                "unit": "GB/s", "frac": q_achieved / HBM_PEAK, "bytes_per_query_model": bq},
