@@ -172,6 +172,27 @@ typedef struct sa_hip_query_stats {
 } sa_hip_query_stats;
 int sa_hip_index_query_stats(const sa_hip_index* idx, sa_hip_query_stats* out);
 
+/* ---- host-side CSV column extractor (reference engine.c:26-96, 461-654) ----------- */
+
+/* One column of an RFC-4180 CSV file, prepared for sa_hip_index_build: the fields lower-cased (ASCII)
+ * with a '\n' after each, the offset of every row's field in that text and the byte offset of every
+ * row in the file (num_rows + 1 entries: the last one is the end of the last row).  The header row
+ * is not indexed.  All arrays are malloc'ed by the callee; release with sa_hip_csv_free. */
+typedef struct sa_hip_csv_column {
+    uint8_t*  text;
+    uint64_t  text_len;
+    uint64_t* row_text_starts;
+    uint64_t* row_file_offsets;
+    uint64_t  num_rows;
+    char*     column_names;      /* num_columns NUL-terminated names, back to back */
+    uint32_t  num_columns;
+    uint32_t  column_index;
+} sa_hip_csv_column;
+int sa_hip_csv_extract_column(const char* path, const char* column, sa_hip_csv_column* out);
+void sa_hip_csv_free(sa_hip_csv_column* col);
+/* Synthetic `id,company_name,country` CSV of BASELINE config 5. */
+int sa_hip_synth_csv(const char* path, uint64_t rows, uint64_t seed);
+
 /* Stable LSD radix sort of n (u64 key, u32 value) records by key bits [begin_bit, end_bit) on
  * `device` (host pointers, sorted in place).  The device sort underneath every build, exported
  * so that it can be tested and profiled on its own.  values == NULL: values are the record

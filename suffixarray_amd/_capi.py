@@ -25,7 +25,7 @@ EXPORTS = [
     "sa_hip_index_stream", "sa_hip_index_get_sa_u32", "sa_hip_index_get_sa_i64",
     "sa_hip_index_get_freq", "sa_hip_query_batch", "sa_hip_query_batch_device",
     "sa_hip_index_get_sa_range", "sa_hip_index_sync", "sa_hip_index_verify", "sa_hip_index_build_stats",
-    "sa_hip_index_query_stats", "sa_hip_sort_pairs", "sa_hip_synth_uniform27", "sa_hip_last_error", "sa_hip_version",
+    "sa_hip_index_query_stats", "sa_hip_csv_extract_column", "sa_hip_csv_free", "sa_hip_synth_csv", "sa_hip_sort_pairs", "sa_hip_synth_uniform27", "sa_hip_last_error", "sa_hip_version",
 ]
 
 
@@ -49,6 +49,12 @@ class BuildStats(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class CsvColumn(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("text_len", C.c_uint64), ("row_text_starts", C.c_void_p),
+                ("row_file_offsets", C.c_void_p), ("num_rows", C.c_uint64), ("column_names", C.c_void_p),
+                ("num_columns", C.c_uint32), ("column_index", C.c_uint32)]
 
 
 class QueryStats(C.Structure):
@@ -130,6 +136,12 @@ def lib():
     L.sa_hip_index_build_stats.argtypes = [vp, C.POINTER(BuildStats)]
     L.sa_hip_index_query_stats.restype = C.c_int
     L.sa_hip_index_query_stats.argtypes = [vp, C.POINTER(QueryStats)]
+    L.sa_hip_csv_extract_column.restype = C.c_int
+    L.sa_hip_csv_extract_column.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(CsvColumn)]
+    L.sa_hip_csv_free.restype = None
+    L.sa_hip_csv_free.argtypes = [C.POINTER(CsvColumn)]
+    L.sa_hip_synth_csv.restype = C.c_int
+    L.sa_hip_synth_csv.argtypes = [C.c_char_p, u64, u64]
     L.sa_hip_sort_pairs.restype = C.c_int
     L.sa_hip_sort_pairs.argtypes = [vp, vp, u64, C.c_int, C.c_int, C.c_int]
     L.sa_hip_synth_uniform27.restype = None
@@ -323,6 +335,29 @@ def get_substring_positions(text, sa, max_suffix_length, substring):
     st.n = t.size
     r = lib().sa_hip_get_substring_positions(t.ctypes.data, C.byref(st), bytes(substring))
     return (r.first, r.second)
+
+
+def csv_extract_column(path, column):
+    """Native RFC-4180 column extractor -> (columns, text bytes, row_text_starts, row_file_offsets)."""
+    col = CsvColumn()
+    check(lib().sa_hip_csv_extract_column(os.fsencode(path), column.encode("utf-8"), C.byref(col)))
+    try:
+        text = C.string_at(col.text, col.text_len) if col.text_len else b""
+        starts = np.frombuffer(C.string_at(col.row_text_starts, col.num_rows * 8), dtype=np.uint64).astype(np.int64) \
+            if col.num_rows else np.zeros(0, np.int64)
+        offs = np.frombuffer(C.string_at(col.row_file_offsets, (col.num_rows + 1) * 8), dtype=np.uint64).astype(np.int64)
+        names, p = [], col.column_names
+        for _ in range(col.num_columns):
+            s = C.string_at(p)
+            names.append(s.decode("utf-8"))
+            p += len(s) + 1
+    finally:
+        lib().sa_hip_csv_free(C.byref(col))
+    return names, text, starts, offs
+
+
+def synth_csv(path, rows, seed=1):
+    check(lib().sa_hip_synth_csv(os.fsencode(path), rows, seed))
 
 
 def sort_pairs(keys, values=None, begin_bit=0, end_bit=64, device=0):

@@ -9,6 +9,7 @@
 #include "radix_sort.hpp"
 #include "sa_build.hpp"
 #include "sa_query.hpp"
+#include "csv_ingest.hpp"
 
 using namespace sa;
 
@@ -412,6 +413,16 @@ int sa_hip_sort_pairs(uint64_t* keys, uint32_t* values, uint64_t n, int begin_bi
     ws.destroy();
     (void)hipStreamDestroy(stream);
     return rc;
+}
+
+int sa_hip_csv_extract_column(const char* path, const char* column, sa_hip_csv_column* out) {
+    if (!path || !column || !out) return fail(SA_HIP_EINVAL, "sa_hip_csv_extract_column: NULL argument");
+    return csv_extract_column(path, column, out);
+}
+void sa_hip_csv_free(sa_hip_csv_column* col) { csv_free(col); }
+int sa_hip_synth_csv(const char* path, uint64_t rows, uint64_t seed) {
+    if (!path) return fail(SA_HIP_EINVAL, "sa_hip_synth_csv: NULL path");
+    return synth_csv(path, rows, seed);
 }
 
 void sa_hip_synth_uniform27(uint8_t* out, uint64_t n, uint64_t seed) {

@@ -61,6 +61,19 @@ def _parse_rows(data: bytes):
 
 
 def extract_column(filename: str, search_column: str) -> ColumnText:
+    """Native extractor (libsa_hip.so, csrc/csv_ingest.hpp); extract_column_py is the same state
+    machine in Python and serves as its reference in the tests."""
+    from . import _capi
+    try:
+        names, text, starts, offs = _capi.csv_extract_column(filename, search_column)
+    except _capi.SaHipError as e:
+        raise ValueError(str(e))
+    out = ColumnText()
+    out.columns, out.text, out.text_row_starts, out.row_file_offsets = names, text, starts, offs
+    return out
+
+
+def extract_column_py(filename: str, search_column: str) -> ColumnText:
     with open(filename, "rb") as f:
         data = f.read()
     rows = _parse_rows(data)

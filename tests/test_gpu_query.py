@@ -134,3 +134,30 @@ def test_cython_api_matches_python_mirror(gpu, tmp_path):
     c = CySuffixArray(csv_file=str(p), search_column="company_name", max_suffix_length=32)
     assert sorted(r["id"] for r in c.query_records("netflix")) == ["1", "3"]
     a.close(); b.close(); c.close()
+
+
+def test_config5_csv_mode_reduced_scale(gpu, tmp_path):
+    """BASELINE config 5 at reduced scale: synthetic company_name CSV, max_suffix_length = 32,
+    query_records against a brute-force scan of the column."""
+    from suffixarray_amd import SuffixArray
+    from suffixarray_amd.csv_ingest import extract_column
+    path = tmp_path / "companies.csv"
+    gpu.synth_csv(str(path), 200_000, 11)
+    col = extract_column(str(path), "company_name")
+    names = col.text.split(b"\n")[:-1]
+    s = SuffixArray(csv_file=str(path), search_column="company_name", max_suffix_length=32)
+    rng = np.random.default_rng(4)
+    queries = [names[i].decode() for i in rng.integers(0, len(names), 60)]
+    queries += [names[i].decode()[1:7] for i in rng.integers(0, len(names), 20)] + ["zzzzqqqq", ", inc."]
+    got = s.query_records_batch([q.upper() for q in queries], k=1000)   # case-insensitive like the reference
+    for q, recs in zip(queries, got):
+        ql = q.lower().encode()[:32]
+        exp = {i + 1 for i, nm in enumerate(names) if ql in nm}
+        ids = {int(r["id"]) for r in recs}
+        if len(exp) <= 1000:
+            assert ids == exp, q
+        else:
+            assert len(ids) == 1000 and ids <= exp, q
+        for r in recs[:5]:
+            assert ql in r["company_name"].lower().encode()
+    s.close()

@@ -73,6 +73,22 @@ def test_pipeline_model_truncated(oracle):
             check_truncated_order(t, got, L)
 
 
+def test_csv_native_matches_python_reference(tmp_path, capi):
+    from suffixarray_amd.csv_ingest import extract_column, extract_column_py
+    p = tmp_path / "t.csv"
+    p.write_bytes(b'id,name,country\n1,Netflix,US\n2,"Acme, Inc.",US\n\n3,"Multi\nLine ""Q""",DE\r\n4,netflix studios,US\n5,,FR\n6')
+    big = tmp_path / "big.csv"
+    capi.synth_csv(str(big), 20000, 3)
+    for path, col in ((p, "name"), (p, "country"), (big, "company_name"), (big, "id")):
+        a, b = extract_column(str(path), col), extract_column_py(str(path), col)
+        assert a.columns == b.columns
+        assert a.text == b.text
+        assert np.array_equal(a.text_row_starts, b.text_row_starts)
+        assert np.array_equal(a.row_file_offsets, b.row_file_offsets)
+    data = big.read_bytes()
+    assert data.startswith(b"id,company_name,country\n") and b'", Inc."' not in data and b', Inc."' in data
+
+
 def test_csv_ingest(tmp_path):
     from suffixarray_amd.csv_ingest import extract_column
     p = tmp_path / "c.csv"
