@@ -237,36 +237,45 @@ __global__ __launch_bounds__(BLD_BLOCK) void compact_kernel(const u8* __restrict
                                                             const u32* __restrict__ src_pos,
                                                             const u32* __restrict__ src_idx, u32* __restrict__ dst_pos,
                                                             u32* __restrict__ dst_idx, u32* __restrict__ dst_gid) {
+    // Each thread owns 16 consecutive elements (one 16-byte load of flags; the flag buffers carry 64
+    // bytes of slack), so one workgroup scan orders the whole tile.
     constexpr int WAVES = BLD_BLOCK / WAVE;
     __shared__ u32 s_a[WAVES], s_h[WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u64 lt = lanemask_lt();
-    const uint2 off = offsets[blockIdx.x];
-    u32 a_off = off.x, h_off = off.y;
-    const u64 base = (u64)blockIdx.x * BLD_TILE;
-    for (int it = 0; it < BLD_ITEMS; ++it) {
-        const u64 j = base + (u64)it * BLD_BLOCK + threadIdx.x;
-        const u32 f = (j < n) ? lf[j] : 0u;
-        const bool act = (f & 2u) != 0;
-        const bool ah = act && (f & 1u);
-        const u64 ba = __ballot(act), bh = __ballot(ah);
-        if (lane == 0) { s_a[wave] = (u32)__popcll(ba); s_h[wave] = (u32)__popcll(bh); }
-        __syncthreads();
-        u32 wa = 0, wh = 0, ta = 0, th = 0;
+    const u64 j0 = (u64)blockIdx.x * BLD_TILE + (u64)threadIdx.x * BLD_ITEMS;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (j0 < n) v = *reinterpret_cast<const uint4*>(lf + j0);
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+    u32 amask = 0, hmask = 0;   // bit k: element j0+k is active / an active head
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            if (w < wave) { wa += s_a[w]; wh += s_h[w]; }
-            ta += s_a[w]; th += s_h[w];
-        }
-        if (act) {
-            const u32 m = a_off + wa + (u32)__popcll(ba & lt);
-            const u32 g = h_off + wh + (u32)__popcll(bh & lt) + (ah ? 1u : 0u) - 1u;
+    for (int k = 0; k < BLD_ITEMS; ++k) {
+        const u32 f = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
+        const bool in = (j0 + k) < n;
+        if (in && (f & 2u)) { amask |= 1u << k; if (f & 1u) hmask |= 1u << k; }
+    }
+    const u32 ca = (u32)__popc(amask), ch = (u32)__popc(hmask);
+    u32 ia = ca, ih = ch;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 ta = __shfl_up(ia, o), th = __shfl_up(ih, o);
+        if (lane >= o) { ia += ta; ih += th; }
+    }
+    if (lane == 63) { s_a[wave] = ia; s_h[wave] = ih; }
+    __syncthreads();
+    const uint2 off = offsets[blockIdx.x];
+    u32 m = off.x + ia - ca, g = off.y + ih - ch;   // exclusive prefix of this thread
+    for (int q = 0; q < wave; ++q) { m += s_a[q]; g += s_h[q]; }
+    if (amask == 0) return;
+#pragma unroll
+    for (int k = 0; k < BLD_ITEMS; ++k) {
+        if (amask & (1u << k)) {
+            if (hmask & (1u << k)) ++g;
+            const u64 j = j0 + k;
             dst_pos[m] = src_pos ? src_pos[j] : (u32)j;
             dst_idx[m] = src_idx[j];
-            dst_gid[m] = g;
+            dst_gid[m] = g - 1u;
+            ++m;
         }
-        a_off += ta; h_off += th;
-        __syncthreads();
     }
 }
 
@@ -581,7 +590,6 @@ struct Builder {
     bool fuse_hist = true;            // SA_HIP_FUSE_HIST: digit histograms inside keygen
     DevBuf partial, dbg;
     bool debug_rounds = false;
-    bool dbg_failed = false;
     // query acceleration (sa_query.hpp): sorted packed keys K + bucket directory
     const u64* qkeys = nullptr;   // points into keys0/keys1 (build) or keys0 (load)
     DevBuf qdir;
@@ -642,7 +650,7 @@ struct Builder {
         if ((rc = keys1.ensure(cap * 8))) return rc;
         if ((rc = vals0.ensure(cap * 4))) return rc;
         if ((rc = vals1.ensure(cap * 4))) return rc;
-        if ((rc = flags.ensure(cap))) return rc;
+        if ((rc = flags.ensure(cap + 64))) return rc;
         if ((rc = counts.ensure((size_t)div_up(cap, BLD_TILE) * sizeof(uint2) + 64))) return rc;
         return 0;
     }
@@ -730,28 +738,7 @@ struct Builder {
         hipLaunchKernelGGL(dbg_dup_kernel, dim3(stream_grid(cnt, 1024)), dim3(256), 0, b->stream, vals, (u64)cnt, b->dbg.as<u32>(), dd);
         (void)hipMemcpyAsync(dups, dd, sizeof dups, hipMemcpyDeviceToHost, b->stream);
         (void)hipStreamSynchronize(b->stream);
-        if (dups[0] && !b->dbg_failed && getenv("SA_HIP_DUMP")) {
-            // dump input and output of the failing pass for offline analysis
-            std::vector<u64> hk(cnt); std::vector<u32> hv(cnt);
-            const void* srcs[4] = {kin, vin, keys, vals};
-            const char* names[4] = {"/tmp/sa_pass_kin.bin", "/tmp/sa_pass_vin.bin", "/tmp/sa_pass_kout.bin", "/tmp/sa_pass_vout.bin"};
-            for (int q = 0; q < 4; ++q) {
-                const bool is_key = (q == 0 || q == 2);
-                (void)hipMemcpy(is_key ? (void*)hk.data() : (void*)hv.data(), srcs[q], (size_t)cnt * (is_key ? 8 : 4), hipMemcpyDeviceToHost);
-                FILE* f = fopen(names[q], "wb");
-                if (f) { fwrite(is_key ? (void*)hk.data() : (void*)hv.data(), is_key ? 8 : 4, cnt, f); fclose(f); }
-            }
-            {   // the radix workspace's small block: tickets | hist[pass][chunk][256] | base[chunk][256]
-                std::vector<u32> hs(RadixWorkspace::small_bytes() / 4);
-                (void)hipMemcpy(hs.data(), b->radix.small, RadixWorkspace::small_bytes(), hipMemcpyDeviceToHost);
-                FILE* g = fopen("/tmp/sa_pass_small.bin", "wb");
-                if (g) { fwrite(hs.data(), 4, hs.size(), g); fclose(g); }
-            }
-            FILE* f = fopen("/tmp/sa_pass_meta.txt", "w");
-            if (f) { fprintf(f, "%u %d %u %d %d\n", cnt, shift, mask, pass, npasses); fclose(f); }
-        }
         if (dups[0]) {
-            b->dbg_failed = true;   // keep the dump of this round's sort input
             fprintf(stderr, "[sa_hip]   sort pass %d/%d over %u records: %llu duplicate values; slot pairs:", pass, npasses, cnt, (unsigned long long)dups[0]);
             for (u64 k = 0; k < dups[0] && k < 24; ++k) fprintf(stderr, " (%llu,%llu)", (unsigned long long)dups[1 + 2 * k], (unsigned long long)dups[2 + 2 * k]);
             fprintf(stderr, "\n");
@@ -872,7 +859,7 @@ struct Builder {
             if ((rc = rkeys1.ensure(m0 * 8))) return rc;
             if ((rc = ridx0.ensure(m0 * 4))) return rc;
             if ((rc = ridx1.ensure(m0 * 4))) return rc;
-            if ((rc = lf.ensure(m0))) return rc;
+            if ((rc = lf.ensure(m0 + 64))) return rc;
             // first compaction: domain = whole SA
             hipLaunchKernelGGL(compact_kernel, dim3(div_up(n32, BLD_TILE)), dim3(BLD_BLOCK), 0, stream, flags.as<u8>(), n32,
                                counts.as<uint2>(), (const u32*)nullptr, (const u32*)sa, apos0.as<u32>(), aidx.as<u32>(),
@@ -917,15 +904,6 @@ struct Builder {
             // sort the active records; aidx is the value array
             SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
             const int end_bit = use_chunk ? 64 : (gb + rb);
-            if (debug_rounds && getenv("SA_HIP_DUMP") && atoi(getenv("SA_HIP_DUMP")) == 2 && !dbg_failed) {
-                std::vector<u64> hk(M); std::vector<u32> hv(M);
-                SA_HIP_CHECK(hipMemcpyAsync(hk.data(), rkeys0.p, (size_t)M * 8, hipMemcpyDeviceToHost, stream));
-                SA_HIP_CHECK(hipMemcpyAsync(hv.data(), ridx0.p, (size_t)M * 4, hipMemcpyDeviceToHost, stream));
-                SA_HIP_CHECK(hipStreamSynchronize(stream));
-                FILE* f = fopen("/tmp/sa_dump_keys.bin", "wb"); if (f) { fwrite(hk.data(), 8, M, f); fclose(f); }
-                f = fopen("/tmp/sa_dump_vals.bin", "wb"); if (f) { fwrite(hv.data(), 4, M, f); fclose(f); }
-                f = fopen("/tmp/sa_dump_meta.txt", "w"); if (f) { fprintf(f, "%u %d %d %u\n", M, begin_bit, end_bit, stats.rounds); fclose(f); }
-            }
             if ((rc = radix_sort_pairs(radix, stream, rkeys0.as<u64>(), ridx0.as<u32>(), rkeys1.as<u64>(), ridx1.as<u32>(), M,
                                        begin_bit, end_bit, false, false, &kres, &vres))) return rc;
             // write back, new heads, counts
