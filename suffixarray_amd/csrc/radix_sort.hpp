@@ -47,7 +47,10 @@ constexpr int NCHUNK = 8;         // look-back chains per pass = XCDs
 constexpr int SORT_ITEMS = 16;    // records per thread
 constexpr int MAX_PASSES = 8;
 constexpr u32 SPIN_LIMIT = 1u << 22;
-constexpr int LB_WINDOW = 8;      // look-back polls in flight per lane
+#ifndef SA_LB_WINDOW
+#define SA_LB_WINDOW 4
+#endif
+constexpr int LB_WINDOW = SA_LB_WINDOW;   // look-back polls in flight per lane
 
 // tile status granule: [63:34] epoch | [33:32] flag | [31:0] count
 constexpr u64 FLAG_AGG = 1, FLAG_INCL = 2;

@@ -113,3 +113,28 @@ def test_long_repeats_67m_many_doubling_rounds(gpu):
             st = idx.build_stats()
             assert st["doubling_rounds"] >= 20, st
             assert idx.verify() == 0, st
+
+
+def test_beyond_int32_max_3e9_verified(gpu):
+    """n = 3e9 > INT32_MAX: past the reach of 32-bit libsais (the reference switches to the true
+    64-bit libsais64 there, libsais64.c:6684); the device pipeline keeps unsigned 32-bit suffix
+    indices up to n = 2^32 - 2.  Checked by the on-device sufcheck and text spot checks of queries."""
+    from suffixarray_amd import synth
+    n = 3_000_000_000
+    t = synth.d1_uniform27(n)
+    with gpu.DeviceIndex(n, 0) as idx:
+        idx.build(t)
+        assert idx.verify() == 0, idx.build_stats()
+        buf, off = synth.query_batch(t, 20000, 16)
+        got = idx.query_batch((buf, off))
+        pats = buf.reshape(-1, 16)
+        for i in np.random.default_rng(0).integers(0, 20000, 200):
+            f, s = int(got["first"][i]), int(got["second"][i])
+            p = pats[i].tobytes()
+            if f == 0xFFFFFFFF:
+                continue
+            if s >= f:
+                for x in idx.sa_range(f, min(s - f + 1, 4)):
+                    assert bytes(t[int(x):int(x) + 16]) == p
+            else:
+                assert bytes(t[int(idx.sa_range(f, 1)[0]):][:16]) > p
