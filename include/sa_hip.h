@@ -160,6 +160,7 @@ typedef struct sa_hip_build_stats {
     uint64_t radix_records;      /* sum over passes of records moved                       */
     uint64_t radix_bytes;        /* algorithmic bytes of those passes: 2*M*(8+4) each      */
     uint64_t active_total;       /* sum over rounds of active-set sizes                    */
+    uint64_t tiny_resolved;      /* suffixes ordered by the tiny-group finisher            */
     double   radix_ms;           /* HIP-event time of all onesweep launches                */
     double   total_ms;           /* HIP-event time of the whole device build               */
 } sa_hip_build_stats;

@@ -45,6 +45,7 @@ class BuildStats(C.Structure):
                 ("initial_chars", C.c_uint32), ("rounds", C.c_uint32), ("chunk_rounds", C.c_uint32),
                 ("doubling_rounds", C.c_uint32), ("final_depth", C.c_uint32), ("radix_passes", C.c_uint32),
                 ("radix_records", C.c_uint64), ("radix_bytes", C.c_uint64), ("active_total", C.c_uint64),
+                ("tiny_resolved", C.c_uint64),
                 ("radix_ms", C.c_double), ("total_ms", C.c_double)]
 
     def as_dict(self):

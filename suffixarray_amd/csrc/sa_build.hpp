@@ -327,6 +327,116 @@ __global__ __launch_bounds__(256) void doubling_keys_kernel(const u32* __restric
     }
 }
 
+// ---- tiny-group finisher ---------------------------------------------------------------------------------
+// Groups of at most TINY_MAX suffixes are ordered by ONE lane with direct text comparisons (8-byte
+// big-endian words from depth h) instead of going through key generation + an 8-pass sort round.  On
+// near-random texts every tied group is a pair, so this replaces the whole refinement round.
+// Full mode: a group is only written when all its members differ within TINY_DEPTH further bytes
+// (otherwise it stays active for the rounds).  Truncated mode compares up to depth L and breaks ties by
+// suffix index = text order, as every stable sort round would.
+constexpr int TINY_MAX = 8;
+constexpr u32 TINY_DEPTH = 64;
+
+// <0, >0: order of suffixes a, b by their bytes [h, h+limit); 0: equal there.  A suffix that ends sorts first.
+__device__ __forceinline__ int cmp_suffix_pair(const u8* __restrict__ text, u64 n, u64 a, u64 b, u64 h, u32 limit) {
+    const u64 pa = a + h, pb = b + h;
+    for (u32 d = 0; d < limit; d += 8) {
+        const u32 want = (limit - d) < 8u ? (limit - d) : 8u;
+        const u64 ra = (pa + d < n) ? n - (pa + d) : 0, rb = (pb + d < n) ? n - (pb + d) : 0;
+        const u32 la = ra < want ? (u32)ra : want, lb = rb < want ? (u32)rb : want;
+        u64 wa = 0, wb = 0;
+        if (la) { __builtin_memcpy(&wa, text + pa + d, 8); wa = __builtin_bswap64(wa); if (la < 8) wa &= ~(~0ull >> (8 * la)); }
+        if (lb) { __builtin_memcpy(&wb, text + pb + d, 8); wb = __builtin_bswap64(wb); if (lb < 8) wb &= ~(~0ull >> (8 * lb)); }
+        if (wa != wb) return wa < wb ? -1 : 1;
+        if (la != lb) return la < lb ? -1 : 1;
+        if (la < want) return 0;   // both ended (only possible for a == b)
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void tiny_groups_kernel(const u8* __restrict__ text, u64 n, const u32* __restrict__ aidx,
+                                                          const u32* __restrict__ gid, const u32* __restrict__ apos, u32 m_count,
+                                                          u64 h, u32 limit, int truncated, u32* __restrict__ sa,
+                                                          u8* __restrict__ gflags, u8* __restrict__ done) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 m = (u64)blockIdx.x * blockDim.x + threadIdx.x; m < m_count; m += stride) {
+        const u32 g = gid[m];
+        if (m > 0 && gid[m - 1] == g) continue;   // only the first member of a group works
+        int size = 1;
+        while (size <= TINY_MAX && m + size < m_count && gid[m + size] == g) ++size;
+        if (size > TINY_MAX) continue;
+        u32 v[TINY_MAX];
+#pragma unroll
+        for (int k = 0; k < TINY_MAX; ++k) v[k] = (k < size) ? aidx[m + k] : 0xFFFFFFFFu;   // sentinel sorts last
+        bool unresolved = false;
+        // 19-comparator sorting network for 8 inputs (static indices: the array stays in registers)
+#define SA_CE(i, j)                                                                                  \
+        {                                                                                            \
+            const u32 x = v[i], y = v[j];                                                            \
+            int c;                                                                                   \
+            if (y == 0xFFFFFFFFu || unresolved) c = -1;                                              \
+            else if (x == 0xFFFFFFFFu) c = 1;                                                        \
+            else {                                                                                   \
+                c = cmp_suffix_pair(text, n, x, y, h, limit);                                        \
+                if (c == 0) { if (truncated) c = x < y ? -1 : 1; else unresolved = true; }           \
+            }                                                                                        \
+            if (c > 0) { v[i] = y; v[j] = x; }                                                       \
+        }
+        SA_CE(0, 1) SA_CE(2, 3) SA_CE(4, 5) SA_CE(6, 7)
+        SA_CE(0, 2) SA_CE(1, 3) SA_CE(4, 6) SA_CE(5, 7)
+        SA_CE(1, 2) SA_CE(5, 6) SA_CE(0, 4) SA_CE(3, 7)
+        SA_CE(1, 5) SA_CE(2, 6)
+        SA_CE(1, 4) SA_CE(3, 6)
+        SA_CE(2, 4) SA_CE(3, 5)
+        SA_CE(3, 4)
+#undef SA_CE
+        // a network does not compare every adjacent pair of its output: make sure the order is strict
+        if (!truncated) {
+#pragma unroll
+            for (int k = 0; k + 1 < TINY_MAX; ++k)
+                if (k + 1 < size && !unresolved && cmp_suffix_pair(text, n, v[k], v[k + 1], h, limit) >= 0) unresolved = true;
+        }
+        if (unresolved) continue;
+#pragma unroll
+        for (int k = 0; k < TINY_MAX; ++k) {
+            if (k < size) {
+                const u32 slot = apos[m + k];
+                sa[slot] = v[k];
+                gflags[slot] = 1;
+                done[m + k] = 1;
+            }
+        }
+    }
+}
+
+// flags + per-tile counts of what the finisher left: lf[m] = done ? 0 : active | (first of its group ? head : 0)
+__global__ __launch_bounds__(BLD_BLOCK) void tiny_flags_kernel(const u32* __restrict__ gid, const u8* __restrict__ done, u32 n,
+                                                               u8* __restrict__ lf, uint2* __restrict__ counts) {
+    __shared__ u32 s_a[BLD_BLOCK / WAVE], s_h[BLD_BLOCK / WAVE];
+    const u64 base = (u64)blockIdx.x * BLD_TILE;
+    u32 ca = 0, ch = 0;
+    for (int it = 0; it < BLD_ITEMS; ++it) {
+        const u64 j = base + (u64)it * BLD_BLOCK + threadIdx.x;
+        if (j < n) {
+            const bool act = done[j] == 0;
+            const bool head = (j == 0) || (gid[j - 1] != gid[j]);
+            lf[j] = act ? (u8)(2 | (head ? 1 : 0)) : (u8)0;
+            ca += act;
+            ch += (act && head);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ca += __shfl_down(ca, o); ch += __shfl_down(ch, o); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_a[wave] = ca; s_h[wave] = ch; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 ta = 0, th = 0;
+        for (int w = 0; w < BLD_BLOCK / WAVE; ++w) { ta += s_a[w]; th += s_h[w]; }
+        counts[blockIdx.x] = make_uint2(ta, th);
+    }
+}
+
 // ---- group starts (ranks) ----------------------------------------------------------------------------------
 // last head value per tile (value = slot of the head: posmap[j] or j), NONE32 if the tile has none
 __global__ __launch_bounds__(BLD_BLOCK) void tile_last_head_kernel(const u8* __restrict__ lf, u32 n,
@@ -588,7 +698,8 @@ struct Builder {
     int chunk_rounds_before_doubling = 2;
     int initial_chars_override = 0;   // SA_HIP_INITIAL_CHARS: 0 = heuristic
     bool fuse_hist = true;            // SA_HIP_FUSE_HIST: digit histograms inside keygen
-    DevBuf partial, dbg;
+    DevBuf partial, dbg, done;
+    bool tiny_finisher = true;        // SA_HIP_TINY: direct-comparison finisher for groups of <= 8
     bool debug_rounds = false;
     // query acceleration (sa_query.hpp): sorted packed keys K + bucket directory
     const u64* qkeys = nullptr;   // points into keys0/keys1 (build) or keys0 (load)
@@ -634,6 +745,7 @@ struct Builder {
         if (const char* e = getenv("SA_HIP_INITIAL_CHARS")) initial_chars_override = atoi(e);
         if (const char* e = getenv("SA_HIP_CHUNK_ROUNDS")) chunk_rounds_before_doubling = atoi(e);
         if (const char* e = getenv("SA_HIP_FUSE_HIST")) fuse_hist = atoi(e) != 0;
+        if (const char* e = getenv("SA_HIP_TINY")) tiny_finisher = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_DEBUG_ROUNDS")) debug_rounds = atoi(e) != 0;
         if (debug_rounds) { radix.debug_hook = &Builder::sort_debug_hook; radix.debug_ctx = this; }
         if ((rc = radix.init(cap, sort_block))) return rc;
@@ -656,7 +768,7 @@ struct Builder {
     }
     void destroy() {
         DevBuf* all[] = {&text, &keys0, &keys1, &vals0, &vals1, &flags, &counts, &small, &isa, &apos0, &apos1, &aidx,
-                         &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir, &dbg};
+                         &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir, &dbg, &done};
         for (DevBuf* b : all) b->release();
         radix.destroy();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
@@ -700,11 +812,8 @@ struct Builder {
         return 0;
     }
 
-    // head/active flags over `cnt` sorted keys (+ optional round write-back), scanned counts.
-    int flags_and_counts(const u64* keys, u32 cnt, u8* lf_out, const u32* apos, const u32* sidx, u32* totals_host) {
-        const u32 tiles = div_up(cnt, BLD_TILE);
-        hipLaunchKernelGGL(flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, keys, cnt, lf_out, counts.as<uint2>(),
-                           apos, sidx, sa, flags.as<u8>());
+    // exclusive scan of counts[0..tiles) + totals to the host
+    int scan_counts(u32 tiles, u32* totals_host) {
         const u32 parts = div_up(tiles, 1024);
         int rc = partial.ensure((size_t)parts * sizeof(uint2) + 64);
         if (rc) return rc;
@@ -712,6 +821,14 @@ struct Builder {
         hipLaunchKernelGGL(counts_scan_partials_kernel, dim3(1), dim3(1024), 0, stream, partial.as<uint2>(), parts, totals_dev());
         hipLaunchKernelGGL(counts_apply_kernel, dim3(parts), dim3(1024), 0, stream, counts.as<uint2>(), tiles, partial.as<uint2>());
         return read_totals(totals_host);
+    }
+
+    // head/active flags over `cnt` sorted keys (+ optional round write-back), scanned counts.
+    int flags_and_counts(const u64* keys, u32 cnt, u8* lf_out, const u32* apos, const u32* sidx, u32* totals_host) {
+        const u32 tiles = div_up(cnt, BLD_TILE);
+        hipLaunchKernelGGL(flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, keys, cnt, lf_out, counts.as<uint2>(),
+                           apos, sidx, sa, flags.as<u8>());
+        return scan_counts(tiles, totals_host);
     }
 
     // isa[idx[j]] = head slot of j's group over a domain of cnt elements
@@ -868,6 +985,32 @@ struct Builder {
         u32* apos_cur = apos0.as<u32>();
         u32* apos_nxt = apos1.as<u32>();
         const int rb = bits_for(n + 1);
+
+        // tiny-group finisher: pairs .. octets of tied suffixes are ordered by direct comparison
+        // (only for sparse active sets: there the alternative is a launch-bound 8-pass round over a few
+        //  records; dense active sets are served better by the bandwidth-bound radix rounds)
+        if (tiny_finisher && M && (u64)M * 16 <= n && (L == 0 || h < L)) {
+            if ((rc = done.ensure((size_t)M + 64))) return rc;
+            SA_HIP_CHECK(hipMemsetAsync(done.p, 0, (size_t)M, stream));
+            const u32 limit = L ? (u32)(L - h) : TINY_DEPTH;
+            hipLaunchKernelGGL(tiny_groups_kernel, dim3(stream_grid(M, 256)), dim3(256), 0, stream, text.as<u8>(), n, aidx.as<u32>(),
+                               gid.as<u32>(), apos_cur, M, h, limit, L ? 1 : 0, sa, flags.as<u8>(), done.as<u8>());
+            const u32 tiles = div_up(M, BLD_TILE);
+            hipLaunchKernelGGL(tiny_flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, gid.as<u32>(), done.as<u8>(), M,
+                               lf.as<u8>(), counts.as<uint2>());
+            if ((rc = scan_counts(tiles, tot))) return rc;
+            stats.tiny_resolved = (u64)M - tot[0];
+            if (tot[0] < M) {
+                if (tot[0]) {
+                    SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
+                    hipLaunchKernelGGL(compact_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, lf.as<u8>(), M, counts.as<uint2>(),
+                                       (const u32*)apos_cur, (const u32*)ridx0.as<u32>(), apos_nxt, aidx.as<u32>(), gid.as<u32>());
+                    u32* t = apos_cur; apos_cur = apos_nxt; apos_nxt = t;
+                }
+                M = tot[0];
+                G = tot[1];
+            }
+        }
 
         while (M && (L == 0 || h < L)) {
             const int gb = bits_for(G);

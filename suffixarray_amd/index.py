@@ -77,6 +77,7 @@ class SuffixArray:
         if len(text) > 0xFFFFFFFE:
             raise ValueError("text exceeds 2^32 - 2 bytes (one index per device)")
         self._text_len = len(text)
+        self._text_bytes = text
         if self._index is not None:
             self._index.close()
         self._index = _capi.DeviceIndex(max(len(text), 1), self.device)
@@ -143,6 +144,61 @@ class SuffixArray:
             rows = self._rows_for_range(int(ranges[j]["first"]), int(ranges[j]["second"]), k)
             res[i] = self._materialise(rows)
         return res
+
+    # -- persistence (the reference's save/load is half-built: engine.c:1098-1165,
+    #    commented-out pyx:310-423).  Versioned directory: meta.json + raw little-endian arrays. ------
+    FORMAT_VERSION = 1
+
+    def save(self, directory: str):
+        """Write the index (text, uint32 suffix array, row tables) so that load() needs no rebuild."""
+        import json
+        if self._index is None:
+            raise RuntimeError("index not built")
+        os.makedirs(directory, exist_ok=True)
+        n = self._index.n
+        self._index.sa_u32().tofile(os.path.join(directory, "sa.u32"))
+        # the indexed (lower-cased) text is re-derived from the source for documents, stored for CSV
+        meta = {"format": "suffixarray_amd", "version": self.FORMAT_VERSION, "mode": self._mode, "n": n,
+                "max_suffix_length": self.max_suffix_length, "columns": self.columns}
+        np.asarray(self._row_starts, dtype=np.int64).tofile(os.path.join(directory, "row_starts.i64"))
+        with open(os.path.join(directory, "text.u8"), "wb") as f:
+            f.write(self._text_bytes)
+        if self._mode == "documents":
+            with open(os.path.join(directory, "documents.json"), "w") as f:
+                json.dump(self._documents, f)
+        else:
+            meta["csv_filename"] = os.path.abspath(self.csv_filename)
+            np.asarray(self._row_file_offsets, dtype=np.int64).tofile(os.path.join(directory, "row_file_offsets.i64"))
+        with open(os.path.join(directory, "meta.json"), "w") as f:
+            json.dump(meta, f)
+
+    @classmethod
+    def load(cls, directory: str, device: int = 0):
+        """Re-open a saved index: uploads text + SA (sa_hip_index_load), no construction."""
+        import json
+        with open(os.path.join(directory, "meta.json")) as f:
+            meta = json.load(f)
+        if meta.get("format") != "suffixarray_amd" or meta.get("version") != cls.FORMAT_VERSION:
+            raise ValueError("not a suffixarray_amd index of a supported version")
+        self = cls(max_suffix_length=meta["max_suffix_length"], device=device)
+        self._mode = meta["mode"]
+        self.columns = meta["columns"]
+        text = np.fromfile(os.path.join(directory, "text.u8"), dtype=np.uint8)
+        sa = np.fromfile(os.path.join(directory, "sa.u32"), dtype=np.uint32)
+        if text.size != meta["n"] or sa.size != meta["n"]:
+            raise ValueError("index files are truncated")
+        self._row_starts = np.fromfile(os.path.join(directory, "row_starts.i64"), dtype=np.int64)
+        self._text_bytes = text.tobytes()
+        self._text_len = text.size
+        if self._mode == "documents":
+            with open(os.path.join(directory, "documents.json")) as f:
+                self._documents = json.load(f)
+        else:
+            self.csv_filename = meta["csv_filename"]
+            self._row_file_offsets = np.fromfile(os.path.join(directory, "row_file_offsets.i64"), dtype=np.int64)
+        self._index = _capi.DeviceIndex(max(text.size, 1), self.device)
+        self._index.load(text, sa, self.max_suffix_length)
+        return self
 
     def close(self):
         if self._index is not None:

@@ -161,3 +161,22 @@ def test_config5_csv_mode_reduced_scale(gpu, tmp_path):
         for r in recs[:5]:
             assert ql in r["company_name"].lower().encode()
     s.close()
+
+
+def test_save_load_roundtrip(gpu, tmp_path):
+    from suffixarray_amd import SuffixArray
+    docs = ["The quick brown fox jumps over the lazy dog", "I am going to the store to buy some milk", "Uhhhhhhhh"]
+    a = SuffixArray(documents=docs, max_suffix_length=32)
+    a.save(str(tmp_path / "idx_docs"))
+    b = SuffixArray.load(str(tmp_path / "idx_docs"))
+    for q in ("the", "milk", "uhh", "zzz", "fox jumps"):
+        assert a.query_records(q) == b.query_records(q)
+    p = tmp_path / "c.csv"
+    p.write_text('id,company_name,country\n1,Netflix,US\n2,"Acme, Inc.",US\n3,netflix studios,US\n')
+    c = SuffixArray(csv_file=str(p), search_column="company_name", max_suffix_length=32)
+    c.save(str(tmp_path / "idx_csv"))
+    d = SuffixArray.load(str(tmp_path / "idx_csv"))
+    assert c.query_records("netflix") == d.query_records("netflix") and len(d.query_records("netflix")) == 2
+    assert d.query_records("acme, inc")[0]["id"] == "2"
+    for x in (a, b, c, d):
+        x.close()
