@@ -52,7 +52,7 @@ def pmc_traffic(n, launches_per_step):
         j = json.load(open(os.path.join(ROOT, "profiles", "pmc_onesweep.json")))
     except Exception:
         return None
-    if n != 1_000_000_000 or launches_per_step != 13:
+    if n != 1_000_000_000 or launches_per_step != j.get("launches_per_build"):
         return None
     return j["traffic_bytes_per_launch"]
 
