@@ -540,6 +540,118 @@ __global__ void widen_kernel(const u32* __restrict__ sa, u64 n, int64_t* __restr
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (int64_t)sa[i];
 }
 
+// ---- on-device verification (sufcheck) ----------------------------------------------
+// SA is the suffix array of T  <=>  it is a permutation of [0,n) and for every adjacent pair
+// (a, b) = (SA[j-1], SA[j]):  T[a] < T[b], or T[a] == T[b] and suffix a+1 sorts before suffix b+1
+// (the empty suffix first) -- by induction over the suffix order the second test may use the
+// ranks ISA[a+1] < ISA[b+1] of the array under test.  O(n) work, 4n bytes of scratch.
+__global__ void verify_scatter_kernel(const u32* __restrict__ sa, u64 n, u32* __restrict__ isa, u64* __restrict__ bad) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const u32 v = sa[j];
+        if (v >= n) atomicAdd((unsigned long long*)bad, 1ull);
+        else isa[v] = (u32)j;
+    }
+}
+__global__ void verify_order_kernel(const u8* __restrict__ text, const u32* __restrict__ sa, const u32* __restrict__ isa,
+                                    u64 n, u64* __restrict__ bad) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u64 local = 0;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const u32 b = sa[j];
+        if (b >= n) continue;                       // counted by the scatter kernel
+        if (isa[b] != (u32)j) { ++local; continue; }   // duplicate value: not a permutation
+        if (j == 0) continue;
+        const u32 a = sa[j - 1];
+        if (a >= n) continue;
+        const u8 ca = text[a], cb = text[b];
+        if (ca > cb) ++local;
+        else if (ca == cb) {
+            if ((u64)a + 1 == n) { /* empty suffix first: fine */ }
+            else if ((u64)b + 1 == n) ++local;
+            else if (isa[a + 1] >= isa[b + 1]) ++local;
+        }
+    }
+    if (local) atomicAdd((unsigned long long*)bad, (unsigned long long)local);
+}
+// truncated order: adjacent suffixes compare <= on their first L bytes (a suffix that ends sorts
+// first), ties in text order
+__global__ void verify_truncated_kernel(const u8* __restrict__ text, const u32* __restrict__ sa, const u32* __restrict__ isa,
+                                        u64 n, u32 L, u64* __restrict__ bad) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u64 local = 0;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const u32 b = sa[j];
+        if (b >= n) continue;
+        if (isa[b] != (u32)j) { ++local; continue; }
+        if (j == 0) continue;
+        const u32 a = sa[j - 1];
+        if (a >= n) continue;
+        int r = 0;
+        for (u32 i = 0; i < L && r == 0; ++i) {
+            const u64 pa = (u64)a + i, pb = (u64)b + i;
+            const int xa = pa < n ? (int)text[pa] : -1, xb = pb < n ? (int)text[pb] : -1;
+            if (xa != xb) r = xa < xb ? -1 : 1;
+            else if (xa < 0) break;
+        }
+        if (r > 0 || (r == 0 && a > b)) ++local;
+    }
+    if (local) atomicAdd((unsigned long long*)bad, (unsigned long long)local);
+}
+
+// ---- debugging aid (SA_HIP_DEBUG_ROUNDS=1): duplicates in a list of suffix indices ------------------
+// mark[v] = 1 + slot of the first occurrence; dups[0] = count, dups[1 + 2k], dups[2 + 2k] = the two slots
+__global__ void dbg_dup_kernel(const u32* __restrict__ idx, u64 m, u32* __restrict__ mark, u64* __restrict__ dups) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const u32 old = atomicCAS(&mark[idx[j]], 0u, (u32)j + 1u);
+        if (old != 0) {
+            const u64 k = atomicAdd((unsigned long long*)dups, 1ull);
+            if (k < 24) { dups[1 + 2 * k] = old - 1; dups[2 + 2 * k] = j; }
+        }
+    }
+}
+
+// ---- query acceleration structures (used by sa_query.hpp) -------------------------------------------
+// keys[j] = packed first k0 characters of suffix sa[j] (for indexes adopted with sa_hip_index_load)
+__global__ __launch_bounds__(256) void gather_keys_kernel(const u8* __restrict__ text, u64 n, CodeMap map, int b, int k0,
+                                                          const u32* __restrict__ sa, u64* __restrict__ keys) {
+    __shared__ u16 s_map[256];
+    s_map[threadIdx.x] = map.code[threadIdx.x];
+    __syncthreads();
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const u64 start = sa[j];
+        u64 key = 0;
+        int sh = 64;
+        for (int i = 0; i < k0; ++i) {
+            const u64 p = start + i;
+            sh -= b;
+            const u64 c = (p < n) ? (u64)s_map[text[p]] : 0ull;
+            key |= c << sh;
+        }
+        keys[j] = key;
+    }
+}
+
+// dir[bkt] = first slot whose key has top-dbits >= bkt, by binary search; dir[2^dbits] = n
+__global__ __launch_bounds__(256) void dir_build_kernel(const u64* __restrict__ keys, u64 n, int dbits, u32* __restrict__ dir) {
+    const u64 nb = (1ull << dbits) + 1;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 bkt = (u64)blockIdx.x * blockDim.x + threadIdx.x; bkt < nb; bkt += stride) {
+        u64 lo = 0, hi = n;
+        if (bkt == nb - 1) lo = n;
+        else {
+            const u64 bound = bkt << (64 - dbits);
+            while (lo < hi) {
+                const u64 mid = (lo + hi) >> 1;
+                if (keys[mid] < bound) lo = mid + 1; else hi = mid;
+            }
+        }
+        dir[bkt] = (u32)lo;
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------
 
 struct DevBuf {
