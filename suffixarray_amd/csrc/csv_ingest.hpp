@@ -12,9 +12,12 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <sched.h>
+
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -74,6 +77,83 @@ inline u32 csv_parse_record(CsvRecordCursor& cur, std::vector<std::string>* fiel
     return fidx;
 }
 
+// One worker's share of the file: the records that START inside [lo, hi).
+struct CsvPart {
+    std::vector<u8> text;
+    std::vector<u64> starts;   // relative to this part's text
+    std::vector<u64> offs;     // file offsets of the rows
+    u64 last_end = 0;
+};
+
+// Fast path of csv_parse_record for one wanted field: the field's bytes go straight into `text`
+// (lower-cased, embedded newlines as spaces).  Same state machine, same return values.
+inline u32 csv_parse_record_into(CsvRecordCursor& cur, u32 want, std::vector<u8>& text, u64* row_start, u64* row_end,
+                                 bool* first_field_empty) {
+    const u8* d = cur.d;
+    const u64 n = cur.n;
+    u64 i = cur.i;
+    *row_start = i;
+    u32 fidx = 0;
+    bool in_quotes = false, f0_empty = true;
+    while (true) {
+        if (i >= n) { ++fidx; break; }
+        const u8 c = d[i];
+        if (in_quotes) {
+            if (c == '"') {
+                if (i + 1 < n && d[i + 1] == '"') {
+                    if (fidx == want) text.push_back('"');
+                    if (fidx == 0) f0_empty = false;
+                    i += 2;
+                    continue;
+                }
+                in_quotes = false; ++i; continue;
+            }
+            if (fidx == want) text.push_back(c == '\n' ? (u8)' ' : (u8)((c >= 65 && c <= 90) ? c + 32 : c));
+            if (fidx == 0) f0_empty = false;
+            ++i;
+            continue;
+        }
+        if (c == '"') { in_quotes = true; ++i; }
+        else if (c == ',') { ++fidx; ++i; }
+        else if (c == '\n' || c == '\r') {
+            ++fidx;
+            if (c == '\r' && i + 1 < n && d[i + 1] == '\n') ++i;
+            ++i;
+            break;
+        } else {
+            if (fidx == want) text.push_back((u8)((c >= 65 && c <= 90) ? c + 32 : c));
+            if (fidx == 0) f0_empty = false;
+            ++i;
+        }
+    }
+    cur.i = i;
+    *row_end = i;
+    *first_field_empty = f0_empty;
+    return fidx;
+}
+
+inline void csv_parse_range(const u8* d, u64 n, u64 begin, u64 hi, u32 ci, CsvPart& part) {
+    CsvRecordCursor cur{d, n, begin};
+    u64 rs, re;
+    bool f0e;
+    part.last_end = begin;
+    part.text.reserve((size_t)((hi - begin) / 2 + 64));
+    part.starts.reserve((size_t)((hi - begin) / 24 + 16));
+    part.offs.reserve((size_t)((hi - begin) / 24 + 16));
+    while (cur.i < hi) {
+        const u64 tpos = part.text.size();
+        const u32 nf = csv_parse_record_into(cur, ci, part.text, &rs, &re, &f0e);
+        if (nf == 1 && f0e) continue;  // blank line (nothing was appended)
+        part.starts.push_back(tpos);
+        part.offs.push_back(rs);
+        part.text.push_back('\n');
+        part.last_end = re;
+    }
+}
+
+// Multi-threaded: the file is cut into byte ranges; the quote parity in front of every range (a '"'
+// toggles it; the doubled quote of RFC-4180 toggles twice) tells whether a newline there is a row
+// terminator, so every worker can find the first row that starts inside its range on its own.
 inline int csv_extract_column(const char* path, const char* column, sa_hip_csv_column* out) {
     memset(out, 0, sizeof *out);
     const int fd = open(path, O_RDONLY);
@@ -85,8 +165,8 @@ inline int csv_extract_column(const char* path, const char* column, sa_hip_csv_c
     void* map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (map == MAP_FAILED) return fail(SA_HIP_ENOMEM, "sa_hip_csv_extract_column: mmap failed", path);
-    (void)madvise(map, n, MADV_SEQUENTIAL);
-    CsvRecordCursor cur{static_cast<const u8*>(map), n, 0};
+    const u8* d = static_cast<const u8*>(map);
+    CsvRecordCursor cur{d, n, 0};
 
     std::vector<std::string> header;
     u64 rs, re;
@@ -95,50 +175,91 @@ inline int csv_extract_column(const char* path, const char* column, sa_hip_csv_c
     int ci = -1;
     for (size_t k = 0; k < header.size(); ++k) if (header[k] == column) { ci = (int)k; break; }
     if (ci < 0) { munmap(map, n); return fail(SA_HIP_EINVAL, "sa_hip_csv_extract_column: column not found", column); }
+    const u64 body = re;   // first byte after the header row
 
-    std::vector<u8> text;
-    text.reserve((size_t)(n / 2));
-    std::vector<u64> starts, offs;
-    std::string field;
-    u64 last_end = re;
-    while (cur.i < n) {
-        field.clear();
-        const u32 nf = csv_parse_record<false>(cur, nullptr, (u32)ci, &field, &rs, &re, &f0e);
-        if (nf == 1 && f0e) continue;  // blank line
-        starts.push_back((u64)text.size());
-        offs.push_back(rs);
-        for (char ch : field) {
-            u8 c = (u8)ch;
-            if (c >= 65 && c <= 90) c += 32;   // suffix_array.pyx:103-107: ASCII only
-            if (c == '\n') c = ' ';
-            text.push_back(c);
+    // ranges
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char* e = getenv("SA_HIP_CSV_THREADS")) hw = (unsigned)atoi(e);
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const unsigned a = (unsigned)CPU_COUNT(&set); if (a && a < hw) hw = a; }
+    if (hw < 1) hw = 1;
+    if (hw > 64) hw = 64;
+    u64 parts_n = (n - body) / (4u << 20) + 1;   // >= 4 MiB per worker
+    if (parts_n > hw) parts_n = hw;
+    std::vector<u64> lo(parts_n + 1);
+    for (u64 k = 0; k <= parts_n; ++k) lo[k] = body + (n - body) * k / parts_n;
+    // pass 1: quote counts per range -> parity in front of each range
+    std::vector<u64> quotes(parts_n, 0);
+    {
+        std::vector<std::thread> th;
+        for (u64 k = 0; k < parts_n; ++k)
+            th.emplace_back([&, k]() { u64 c = 0; for (u64 i = lo[k]; i < lo[k + 1]; ++i) c += (d[i] == '"'); quotes[k] = c; });
+        for (auto& t : th) t.join();
+    }
+    // start of the first record of every range: after the first newline outside quotes at or after lo[k]
+    // (a record that starts exactly at lo[k] is recognised by the terminator just before it)
+    std::vector<u64> begin(parts_n + 1, n);
+    begin[0] = body;
+    {
+        u64 parity = 0;
+        for (u64 k = 1; k < parts_n; ++k) {
+            parity ^= (quotes[k - 1] & 1);
+            u64 i = lo[k];
+            bool inq = parity != 0;
+            // step back one byte: if the previous byte terminates a row (outside quotes), lo[k] starts a row
+            u64 b = n;
+            if (!inq && i > body && (d[i - 1] == '\n' || (d[i - 1] == '\r' && !(i < n && d[i] == '\n')))) b = i;
+            for (; b == n && i < n; ++i) {
+                const u8 c = d[i];
+                if (c == '"') inq = !inq;
+                else if (!inq && c == '\n') b = i + 1;
+                else if (!inq && c == '\r' && !(i + 1 < n && d[i + 1] == '\n')) b = i + 1;
+            }
+            begin[k] = b;
         }
-        text.push_back('\n');
-        last_end = re;
+        begin[parts_n] = n;
+        for (u64 k = parts_n; k-- > 1;) if (begin[k] > begin[k + 1]) begin[k] = begin[k + 1];
+    }
+    // pass 2: parse the rows that start in [begin[k], begin[k+1])
+    std::vector<CsvPart> part(parts_n);
+    {
+        std::vector<std::thread> th;
+        for (u64 k = 0; k < parts_n; ++k)
+            th.emplace_back([&, k]() { if (begin[k] < begin[k + 1]) csv_parse_range(d, n, begin[k], begin[k + 1], (u32)ci, part[k]); });
+        for (auto& t : th) t.join();
     }
     munmap(map, n);
-    offs.push_back(starts.empty() ? 0 : last_end);
 
-    out->text_len = text.size();
-    out->num_rows = starts.size();
+    u64 tlen = 0, rows = 0, last_end = 0;
+    for (auto& p : part) { tlen += p.text.size(); rows += p.starts.size(); if (!p.starts.empty()) last_end = p.last_end; }
+    out->text_len = tlen;
+    out->num_rows = rows;
     out->num_columns = (u32)header.size();
     out->column_index = (u32)ci;
     size_t names_len = 0;
     for (auto& h : header) names_len += h.size() + 1;
-    out->text = (uint8_t*)malloc(text.size() ? text.size() : 1);
-    out->row_text_starts = (uint64_t*)malloc((starts.size() ? starts.size() : 1) * sizeof(uint64_t));
-    out->row_file_offsets = (uint64_t*)malloc(offs.size() * sizeof(uint64_t));
+    out->text = (uint8_t*)malloc(tlen ? tlen : 1);
+    out->row_text_starts = (uint64_t*)malloc((rows ? rows : 1) * sizeof(uint64_t));
+    out->row_file_offsets = (uint64_t*)malloc((rows + 1) * sizeof(uint64_t));
     out->column_names = (char*)malloc(names_len ? names_len : 1);
     if (!out->text || !out->row_text_starts || !out->row_file_offsets || !out->column_names) {
         free(out->text); free(out->row_text_starts); free(out->row_file_offsets); free(out->column_names);
         memset(out, 0, sizeof *out);
         return fail(SA_HIP_ENOMEM, "sa_hip_csv_extract_column: out of host memory");
     }
-    if (!text.empty()) memcpy(out->text, text.data(), text.size());
-    if (!starts.empty()) memcpy(out->row_text_starts, starts.data(), starts.size() * sizeof(u64));
-    memcpy(out->row_file_offsets, offs.data(), offs.size() * sizeof(u64));
-    char* p = out->column_names;
-    for (auto& h : header) { memcpy(p, h.c_str(), h.size() + 1); p += h.size() + 1; }
+    u64 toff = 0, roff = 0;
+    for (auto& p : part) {
+        if (!p.text.empty()) memcpy(out->text + toff, p.text.data(), p.text.size());
+        for (size_t r = 0; r < p.starts.size(); ++r) {
+            out->row_text_starts[roff + r] = toff + p.starts[r];
+            out->row_file_offsets[roff + r] = p.offs[r];
+        }
+        toff += p.text.size();
+        roff += p.starts.size();
+    }
+    out->row_file_offsets[rows] = rows ? last_end : 0;
+    char* pn = out->column_names;
+    for (auto& h : header) { memcpy(pn, h.c_str(), h.size() + 1); pn += h.size() + 1; }
     return 0;
 }
 
