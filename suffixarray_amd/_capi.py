@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsa_hip.so")
+LIB_PATH = os.environ.get("SA_HIP_LIB", os.path.join(_HERE, "libsa_hip.so"))   # SA_HIP_LIB: A/B builds in tools/
 
 PAIR_DTYPE = np.dtype([("first", "<u4"), ("second", "<u4")])
 UINT32_MAX = 0xFFFFFFFF

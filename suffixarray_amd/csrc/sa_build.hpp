@@ -280,6 +280,47 @@ __global__ __launch_bounds__(BLD_BLOCK) void compact_kernel(const u8* __restrict
     }
 }
 
+// Dense variant (a large share of the domain is active): elements are visited in lane-strided
+// order so that the reads of src_pos / src_idx and the compacted stores coalesce; costs one
+// workgroup scan per 256 elements, which the sparse variant above avoids.
+__global__ __launch_bounds__(BLD_BLOCK) void compact_dense_kernel(const u8* __restrict__ lf, u32 n,
+                                                                  const uint2* __restrict__ offsets,
+                                                                  const u32* __restrict__ src_pos,
+                                                                  const u32* __restrict__ src_idx, u32* __restrict__ dst_pos,
+                                                                  u32* __restrict__ dst_idx, u32* __restrict__ dst_gid) {
+    constexpr int WAVES = BLD_BLOCK / WAVE;
+    __shared__ u32 s_a[WAVES], s_h[WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 lt = lanemask_lt();
+    const uint2 off = offsets[blockIdx.x];
+    u32 a_off = off.x, h_off = off.y;
+    const u64 base = (u64)blockIdx.x * BLD_TILE;
+    for (int it = 0; it < BLD_ITEMS; ++it) {
+        const u64 j = base + (u64)it * BLD_BLOCK + threadIdx.x;
+        const u32 f = (j < n) ? lf[j] : 0u;
+        const bool act = (f & 2u) != 0;
+        const bool ah = act && (f & 1u);
+        const u64 ba = __ballot(act), bh = __ballot(ah);
+        if (lane == 0) { s_a[wave] = (u32)__popcll(ba); s_h[wave] = (u32)__popcll(bh); }
+        __syncthreads();
+        u32 wa = 0, wh = 0, ta = 0, th = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            if (w < wave) { wa += s_a[w]; wh += s_h[w]; }
+            ta += s_a[w]; th += s_h[w];
+        }
+        if (act) {
+            const u32 m = a_off + wa + (u32)__popcll(ba & lt);
+            const u32 g = h_off + wh + (u32)__popcll(bh & lt) + (ah ? 1u : 0u) - 1u;
+            dst_pos[m] = src_pos ? src_pos[j] : (u32)j;
+            dst_idx[m] = src_idx[j];
+            dst_gid[m] = g;
+        }
+        a_off += ta; h_off += th;
+        __syncthreads();
+    }
+}
+
 // ---- round keys ------------------------------------------------------------------------------------------
 // chunk round: key = gid << (64-gb) | next kc characters of the text after depth h (b bits each).
 // The characters are fetched as unaligned 8-byte words (the text is zero padded, so reads past n
@@ -819,6 +860,18 @@ struct Builder {
         return read_totals(totals_host);
     }
 
+    // compaction of the active elements of a domain of `cnt` elements, `active` of them active
+    void launch_compact(const u8* lf_in, u32 cnt, u32 active, const u32* src_pos, const u32* src_idx, u32* dst_pos,
+                        u32* dst_idx, u32* dst_gid) {
+        const u32 tiles = div_up(cnt, BLD_TILE);
+        if ((u64)active * 8 >= cnt)
+            hipLaunchKernelGGL(compact_dense_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, lf_in, cnt, counts.as<uint2>(), src_pos,
+                               src_idx, dst_pos, dst_idx, dst_gid);
+        else
+            hipLaunchKernelGGL(compact_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, lf_in, cnt, counts.as<uint2>(), src_pos,
+                               src_idx, dst_pos, dst_idx, dst_gid);
+    }
+
     // head/active flags over `cnt` sorted keys (+ optional round write-back), scanned counts.
     int flags_and_counts(const u64* keys, u32 cnt, u8* lf_out, const u32* apos, const u32* sidx, u32* totals_host) {
         const u32 tiles = div_up(cnt, BLD_TILE);
@@ -974,9 +1027,7 @@ struct Builder {
             if ((rc = ridx1.ensure(m0 * 4))) return rc;
             if ((rc = lf.ensure(m0 + 64))) return rc;
             // first compaction: domain = whole SA
-            hipLaunchKernelGGL(compact_kernel, dim3(div_up(n32, BLD_TILE)), dim3(BLD_BLOCK), 0, stream, flags.as<u8>(), n32,
-                               counts.as<uint2>(), (const u32*)nullptr, (const u32*)sa, apos0.as<u32>(), aidx.as<u32>(),
-                               gid.as<u32>());
+            launch_compact(flags.as<u8>(), n32, M, nullptr, sa, apos0.as<u32>(), aidx.as<u32>(), gid.as<u32>());
         }
         u32* apos_cur = apos0.as<u32>();
         u32* apos_nxt = apos1.as<u32>();
@@ -999,8 +1050,7 @@ struct Builder {
             if (tot[0] < M) {
                 if (tot[0]) {
                     SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
-                    hipLaunchKernelGGL(compact_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, lf.as<u8>(), M, counts.as<uint2>(),
-                                       (const u32*)apos_cur, (const u32*)ridx0.as<u32>(), apos_nxt, aidx.as<u32>(), gid.as<u32>());
+                    launch_compact(lf.as<u8>(), M, tot[0], apos_cur, ridx0.as<u32>(), apos_nxt, aidx.as<u32>(), gid.as<u32>());
                     u32* t = apos_cur; apos_cur = apos_nxt; apos_nxt = t;
                 }
                 M = tot[0];
@@ -1074,9 +1124,7 @@ struct Builder {
             h = h_next;
             const u32 M_next = tot[0];
             if (M_next && (L == 0 || h < L)) {
-                hipLaunchKernelGGL(compact_kernel, dim3(div_up(M, BLD_TILE)), dim3(BLD_BLOCK), 0, stream, lf.as<u8>(), M,
-                                   counts.as<uint2>(), (const u32*)apos_cur, (const u32*)vres, apos_nxt, aidx.as<u32>(),
-                                   gid.as<u32>());
+                launch_compact(lf.as<u8>(), M, M_next, apos_cur, vres, apos_nxt, aidx.as<u32>(), gid.as<u32>());
                 u32* t = apos_cur; apos_cur = apos_nxt; apos_nxt = t;
             }
             M = M_next;
