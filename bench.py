@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark of the hot path (BASELINE.json metric):
 SA build chars/s (N = 1e9) + batched queries/s (Q = 1e6) on one MI355X, % of HBM roofline.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--n CHARS] [--q QUERIES]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--chars CHARS] [--queries QUERIES]
 
 A "step" = one device build of the suffix array of the N-char synthetic text D1 (uniform27,
 SURVEY.md 8d; text resident in HBM before the timed region) + one batch of Q 16-byte queries
@@ -98,11 +98,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1_000_000_000)
-    ap.add_argument("--q", type=int, default=1_000_000)
+    ap.add_argument("--chars", "--n", dest="n", type=int, default=1_000_000_000)
+    ap.add_argument("--queries", "--q", dest="q", type=int, default=1_000_000)
     ap.add_argument("--pattern-len", type=int, default=16)
     ap.add_argument("--cpu-sample", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exercise-dist", action="store_true",
+                    help="run the multi-GPU code paths (RCCL init, result all-gather, index broadcast) even at world size 1")
     args = ap.parse_args()
 
     import torch
@@ -117,7 +119,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or (args.exercise_dist and "RANK" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     N, Q, m = args.n, args.q, args.pattern_len
@@ -131,8 +134,10 @@ def main():
     off_t = torch.from_numpy(q_off.view(np.int64)).to(dev)
     out_t = torch.zeros(2 * Q, dtype=torch.int32, device=dev)
 
+    gathered = torch.empty(world * 2 * Q, dtype=torch.int32, device=dev) if use_dist else None
+
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -140,6 +145,8 @@ def main():
         idx.build_device(text_dev, N, 0)
         idx.query_batch_device(pat_t.data_ptr(), off_t.data_ptr(), Q, out_t.data_ptr())
         idx.sync()
+        if use_dist:   # hits gathered on every rank (8 bytes per query over RCCL)
+            dist.all_gather_into_tensor(gathered, out_t)
 
     for _ in range(args.warmup):
         step()
@@ -156,7 +163,7 @@ def main():
         query_ms += idx.query_stats()["kernel_ms"]
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt, build_ms, query_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt, build_ms_max, query_ms_max = tmax.tolist()
@@ -166,7 +173,7 @@ def main():
 
     # one-time replication cost (north_star): RCCL broadcast of text + SA from rank 0
     bcast_ms = None
-    if world > 1:
+    if use_dist:
         sa_t = torch.empty(N, dtype=torch.int32, device=dev)
         tx_t = torch.empty(N, dtype=torch.uint8, device=dev)
         barrier()
@@ -232,7 +239,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(text, q_buf, q_off, min(args.cpu_sample, N), min(Q, 1_000_000))
         print(json.dumps(line))
     idx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
