@@ -18,6 +18,19 @@ ORACLE_SO = os.path.join(_HERE, "libsa_oracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libsa_ref.so")
 
 
+def usable_threads(cap=16):
+    """OpenMP team size that fits this process: affinity mask, cgroup CPU quota, and `cap`.  Letting
+    OpenMP default to every core of the machine oversubscribes the GPU box's 16-core share badly."""
+    n = max(1, len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
 def build(quiet=True):
     """Compile the oracle (always) and oracle/_ref (only where /root/reference exists)."""
     subprocess.run(["make", "-C", _HERE], check=True,
@@ -106,11 +119,14 @@ class Oracle:
                                                     max_suffix_length, q.ctypes.data, q.size)
         return (r.first, r.second)
 
-    def query_batch(self, text, sa, max_suffix_length, patterns, threads=0):
+    def query_batch(self, text, sa, max_suffix_length, patterns, threads=None):
+        """threads: None -> 1 for small batches, usable_threads() for large ones; 0 -> OpenMP default."""
         t = _u8(text)
         s = np.ascontiguousarray(sa, dtype=np.uint32)
         buf, off = patterns if isinstance(patterns, tuple) else pack_patterns(patterns)
         q = off.size - 1
+        if threads is None:
+            threads = 1 if q < 20000 else usable_threads()
         out = np.zeros(q, dtype=PAIR_DTYPE)
         buf = np.ascontiguousarray(buf)
         if buf.size == 0:

@@ -64,6 +64,31 @@ __global__ __launch_bounds__(256) void byte_hist_kernel(const u8* __restrict__ t
     if (c) atomicAdd((unsigned long long*)&hist[threadIdx.x], (unsigned long long)c);
 }
 
+// ---- pilot: how repetitive is the text at the key length the i.i.d. estimate would choose? -------------
+// PILOT_SAMPLES evenly spaced windows of `w` raw bytes are inserted into a hash set (linear probing,
+// 64-bit CAS); *dups counts the windows that were already present.  On an i.i.d. text practically none
+// are; on word / name / log-like texts a large share is, and the initial sort then takes the longest
+// key that fits instead (fewer, smaller refinement rounds).
+constexpr u32 PILOT_SAMPLES = 1u << 17;
+constexpr u32 PILOT_SLOTS = 1u << 20;
+__global__ __launch_bounds__(256) void pilot_kernel(const u8* __restrict__ text, u64 n, int w, unsigned long long* __restrict__ table,
+                                                    u32* __restrict__ dups) {
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= PILOT_SAMPLES) return;
+    const u64 p = (n - 8) / PILOT_SAMPLES * s;          // n >= 16 * PILOT_SAMPLES
+    u64 v;
+    __builtin_memcpy(&v, text + p, 8);
+    if (w < 8) v &= (1ull << (8 * w)) - 1ull;
+    const unsigned long long key = v * 0x9E3779B97F4A7C15ull | 1ull;   // odd multiplier: injective; never 0
+    u32 slot = (u32)(key >> 40) & (PILOT_SLOTS - 1);
+    for (int probe = 0; probe < 16; ++probe) {
+        const unsigned long long old = atomicCAS(&table[slot], 0ull, key);
+        if (old == 0ull) return;
+        if (old == key) { atomicAdd(dups, 1u); return; }
+        slot = (slot + 1) & (PILOT_SLOTS - 1);
+    }
+}
+
 // ---- initial keys: key[i] = codes of T[i..i+k0) packed MSB-first, b bits each ----------------------
 // One workgroup stages BLD_TILE + k0 text bytes as codes in LDS (16-byte global loads), every
 // thread then assembles the keys of 16 positions (stride 256 -> 8-byte coalesced stores).
@@ -734,6 +759,8 @@ struct Builder {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int chunk_rounds_before_doubling = 2;
     int initial_chars_override = 0;   // SA_HIP_INITIAL_CHARS: 0 = heuristic
+    double pilot_dup_share = 0.0;     // share of sampled 8-byte windows seen before (pilot_kernel)
+    DevBuf pilot;
     bool fuse_hist = true;            // SA_HIP_FUSE_HIST: digit histograms inside keygen
     DevBuf partial, dbg, done;
     bool tiny_finisher = true;        // SA_HIP_TINY: direct-comparison finisher for groups of <= 8
@@ -759,7 +786,7 @@ struct Builder {
                 const double need = std::log(0.02 / (double)n) / std::log(c2);
                 int kk = (int)std::ceil(need);
                 if (kk < 1) kk = 1;
-                if (kk < kmax) {
+                if (kk < kmax && pilot_dup_share <= 0.03) {
                     const int passes = (kk * b + RADIX_BITS - 1) / RADIX_BITS;
                     kk = (passes * RADIX_BITS) / b;
                     k = kk < kmax ? kk : kmax;
@@ -805,7 +832,7 @@ struct Builder {
     }
     void destroy() {
         DevBuf* all[] = {&text, &keys0, &keys1, &vals0, &vals1, &flags, &counts, &small, &isa, &apos0, &apos1, &aidx,
-                         &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir, &dbg, &done};
+                         &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir, &dbg, &done, &pilot};
         for (DevBuf* b : all) b->release();
         radix.destroy();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
@@ -821,7 +848,21 @@ struct Builder {
         SA_HIP_CHECK(hipMemsetAsync(dh, 0, 256 * sizeof(u64), stream));
         if (n) hipLaunchKernelGGL(byte_hist_kernel, dim3(stream_grid(n, 256 * 64)), dim3(256), 0, stream, text.as<u8>(), n, dh);
         SA_HIP_CHECK(hipMemcpyAsync(freq, dh, sizeof freq, hipMemcpyDeviceToHost, stream));
+        // pilot (independent of the histogram: raw bytes), only for texts large enough to matter
+        u32 pilot_dups = 0;
+        pilot_dup_share = 0.0;
+        const bool run_pilot = n >= (u64)16 * PILOT_SAMPLES;
+        if (run_pilot) {
+            int rc = pilot.ensure((size_t)PILOT_SLOTS * 8 + 64);
+            if (rc) return rc;
+            SA_HIP_CHECK(hipMemsetAsync(pilot.p, 0, (size_t)PILOT_SLOTS * 8 + 64, stream));
+            u32* pd = reinterpret_cast<u32*>(pilot.as<u8>() + (size_t)PILOT_SLOTS * 8);
+            hipLaunchKernelGGL(pilot_kernel, dim3(PILOT_SAMPLES / 256), dim3(256), 0, stream, text.as<u8>(), n, 8,
+                               pilot.as<unsigned long long>(), pd);
+            SA_HIP_CHECK(hipMemcpyAsync(&pilot_dups, pd, 4, hipMemcpyDeviceToHost, stream));
+        }
         SA_HIP_CHECK(hipStreamSynchronize(stream));
+        if (run_pilot) pilot_dup_share = (double)pilot_dups / (double)PILOT_SAMPLES;
         sigma = 0;
         memset(&map, 0, sizeof map);
         for (int c = 0; c < 256; ++c)

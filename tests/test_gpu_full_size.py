@@ -13,7 +13,8 @@ def _cpu_sa(text, oracle):
     import os
     from oracle.oracle import Ref
     if Ref.available():
-        threads = max(1, min(16, len(os.sched_getaffinity(0))))   # the GPU box's CPU share
+        from oracle.oracle import usable_threads
+        threads = usable_threads()   # the GPU box's CPU share
         return Ref().libsais(text, threads=threads).astype(np.uint32), f"reference libsais_omp({threads})"
     return oracle.sais(text).astype(np.uint32), "oracle port"
 
@@ -81,7 +82,7 @@ def test_config3_n1e9_properties(gpu, oracle):
         assert np.array_equal(sa64[lo:hi], sa[lo:hi].astype(np.int64))
     del sa64
     # ranges: every one of the 1M against the oracle restatement of get_substring_positions
-    exp = oracle.query_batch(t, sa, 0xFFFFFFFF, (buf, off), threads=0)
+    exp = oracle.query_batch(t, sa, 0xFFFFFFFF, (buf, off))
     assert np.array_equal(got, exp)
     # and directly against the text for a sample: hits carry the pattern, the neighbours do not
     pats = buf.reshape(q, m)
