@@ -172,15 +172,31 @@ def main():
     last = idx.build_stats()
 
     # one-time replication cost (north_star): RCCL broadcast of text + SA from rank 0
-    bcast_ms = None
+    # The north-star replication path, outside the timed steps: rank 0's index (text + SA) reaches the
+    # other GPUs by one RCCL broadcast per tensor, every rank adopts the copy (sa_hip_index_load_device)
+    # and answers its slice of the batch from it; the ranges must equal those of its own build.
+    bcast_ms, replica_ok = None, None
     if use_dist:
-        sa_t = torch.empty(N, dtype=torch.int32, device=dev)
-        tx_t = torch.empty(N, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            tx_t = torch.from_numpy(text).to(dev)
+            sa_t = torch.from_numpy(idx.sa_u32().view(np.int32)).to(dev)
+        else:
+            tx_t = torch.empty(N, dtype=torch.uint8, device=dev)
+            sa_t = torch.empty(N, dtype=torch.int32, device=dev)
         barrier()
         b0 = time.perf_counter()
         broadcast_index(tx_t, sa_t, src=0)
         barrier()
         bcast_ms = (time.perf_counter() - b0) * 1e3
+        own = out_t.clone()
+        rep = _capi.DeviceIndex(N, local_rank)
+        rep.load_device(tx_t.data_ptr(), sa_t.data_ptr(), N, 0)
+        rep.query_batch_device(pat_t.data_ptr(), off_t.data_ptr(), Q, out_t.data_ptr())
+        rep.sync()
+        ok_t = torch.tensor([1 if torch.equal(own, out_t) else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        replica_ok = bool(ok_t.item())
+        rep.close()
         del sa_t, tx_t
 
     # correctness gate inside the bench: the SA of the last step is a suffix array (spot checks)
@@ -224,6 +240,7 @@ def main():
             "queries_per_s": queries_per_s,
             "query_ms": query_ms_max / steps,
             "broadcast_ms": bcast_ms,
+            "replica_query_ok": replica_ok,
             "build_stats": {k: last[k] for k in ("sigma", "bits_per_symbol", "initial_chars", "rounds", "chunk_rounds",
                                                  "doubling_rounds", "final_depth", "radix_passes", "active_total")},
             "roofline": {"bound": "hbm", "kernel": "radix_onesweep_kernel", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
