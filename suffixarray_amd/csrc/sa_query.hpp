@@ -14,8 +14,8 @@
 //                search step is ONE aligned 8-byte load, no indirection, and the last three steps
 //                of a descent fall into one 64-byte sector.
 //   dir  u32[2^dbits + 1]  bucket directory over the top dbits of K (first slot of every bucket):
-//                one load replaces the top ~20 levels of the descent (it stays resident in the
-//                L2 / Infinity Cache across the batch).
+//                one load replaces the top ~24 levels of the descent (it stays resident in the
+//                Infinity Cache across the batch).
 //   SA,T only for the final disambiguation beyond k0 characters, inside the (usually 0..2 slot)
 //                range that K leaves.
 // The lower-bound descent remembers the tightest strictly-greater slot, so the upper bound
