@@ -38,6 +38,7 @@
 // shared code or structure.
 #pragma once
 #include "common.hpp"
+#include <type_traits>
 
 namespace sa {
 
@@ -50,7 +51,6 @@ constexpr u32 SPIN_LIMIT = 1u << 22;
 #ifndef SA_LB_WINDOW
 #define SA_LB_WINDOW 4
 #endif
-constexpr int LB_WINDOW = SA_LB_WINDOW;   // look-back polls in flight per lane
 
 // tile status granule: [63:34] epoch | [33:32] flag | [31:0] count
 constexpr u64 FLAG_AGG = 1, FLAG_INCL = 2;
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256) void radix_scan_hist_kernel(const u32* __restr
 // ---- decoupled look-back with a window of LB_WINDOW predecessors in flight -------------------------
 // A granule only ever goes  not-ready -> AGG -> INCL  and both published forms stay valid for
 // whoever read them, so window entries loaded early never go stale in a harmful way.
+template <int LB_WINDOW = SA_LB_WINDOW>
 __device__ __forceinline__ u32 lookback_prefix(const u64* __restrict__ status, u32 tile, u32 first_tile, u32 digit,
                                                u32 epoch, DeviceStatus* dstat) {
     u32 prefix = 0;
@@ -212,24 +213,218 @@ __device__ __forceinline__ u32 lookback_prefix(const u64* __restrict__ status, u
 }
 
 // ---- the pass -----------------------------------------------------------------------------------
-// ABL: ablation mask for tools/sortbench.hip only (0 in the product): 1 = no look-back,
+// Written against the ISA: the first formulation of this kernel compiled to 2,800 vector-ALU
+// instructions per wave and, with 16 waves per CU, was as much VALU-bound as HBM-bound.  This one
+// needs about 1,400:
+//   * ranking: per digit bit ONE v_bfe_i32 (e = -bit), ONE v_cmp (the ballot) and one three-input
+//     bit operation (v_bitop3) per 32-bit half of the peer mask, peers &= ~(ballot ^ e); lane rank
+//     with v_mbcnt; two records interleaved.  The per-wave digit counters are plain LDS words
+//     (volatile generic pointers compiled to flat loads/stores with vmcnt(0) waits);
+//   * the tile-local digit start is folded into the per-wave counters: one LDS read per record
+//     when the keys are placed;
+//   * full tiles run without any bounds checks (only the last tile of the input is partial);
+//   * destination chunk of a record (for the next pass's histogram) from a per-digit
+//     {base chunk, threshold} word instead of seven compares per record.
+// ABL: ablation mask for tools/sortbench.hip only (0 in the product): 1 = no look-back (every tile
+// of a chunk then writes to the same place: the stores stay in cache, NOT a bandwidth figure),
 // 4 = no values, 8 = stores not scattered (streaming copy), 16 = no next-pass histogram.
+__device__ __forceinline__ u32 digit_of(u64 key, int shift, u32 mask) { return (u32)(key >> shift) & mask; }
+
+template <bool FULL, int BLOCK, int ABL>
+__device__ __forceinline__ void onesweep_tile(const SortPassArgs& a, const u32 tile, const u32 chunk, const u32 tile_n,
+                                              u64* s_keys, u32* s_whist, uint2* s_tab, u32* s_wsum) {
+    constexpr int WAVES = BLOCK / WAVE;
+    constexpr int TILE = BLOCK * SORT_ITEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 first_tile = chunk * a.g.tpc;
+    const u64 tile_base = (u64)tile * TILE;
+    const u32 woff = (u32)wave * (WAVE * SORT_ITEMS) + lane;   // tile-local index of this lane's record 0
+
+    // 1. load (wave-striped): wave w owns records [w*64*ITEMS, (w+1)*64*ITEMS) of the tile
+    u64 key[SORT_ITEMS];
+    const u64* kin = a.keys_in + tile_base;
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        const u32 p = woff + j * WAVE;
+        key[j] = (FULL || p < tile_n) ? kin[p] : ~0ull;
+    }
+
+    // 2. per-wave stable ranking with ballot match masks, two records at a time
+    u32 rd[SORT_ITEMS];   // rank within (wave, digit) | digit << 16
+    u32* wh = s_whist + wave * RADIX;
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j += 2) {
+        bool valid[2];
+        u32 d[2], lo[2], hi[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            valid[i] = FULL || (woff + (j + i) * WAVE) < tile_n;
+            d[i] = digit_of(key[j + i], a.shift, a.mask);
+            lo[i] = ~0u; hi[i] = ~0u;
+            if (!FULL) { const u64 vm = __ballot(valid[i]); lo[i] = (u32)vm; hi[i] = (u32)(vm >> 32); }
+        }
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; ++b) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                u32 e = (u32)__builtin_amdgcn_sbfe((int)d[i], b, 1);   // all ones where the bit is set
+                asm("" : "+v"(e));       // keep e, the compare on it and the two bit operations as written
+                const u64 m = __ballot(e != 0);
+                lo[i] &= ~((u32)m ^ e);
+                hi[i] &= ~((u32)(m >> 32) ^ e);
+                asm("" : "+v"(lo[i]), "+v"(hi[i]));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const u32 below = __builtin_amdgcn_mbcnt_hi(hi[i], __builtin_amdgcn_mbcnt_lo(lo[i], 0u));
+            const u32 total = (u32)__popc(lo[i]) + (u32)__popc(hi[i]);
+            const u32 prior = wh[d[i]];
+            __builtin_amdgcn_wave_barrier();
+            if (valid[i] && below == 0) wh[d[i]] = prior + total;
+            __builtin_amdgcn_wave_barrier();
+            rd[j + i] = (prior + below) | (d[i] << 16);
+        }
+    }
+    // values are fetched only now: their latency hides behind the count / look-back phase and
+    // they do not occupy registers during ranking
+    u32 val[SORT_ITEMS];
+    if (a.vals_in) {
+        const u32* vin = a.vals_in + tile_base;
+#pragma unroll
+        for (int j = 0; j < SORT_ITEMS; ++j) {
+            const u32 p = woff + j * WAVE;
+            val[j] = (FULL || p < tile_n) ? vin[p] : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SORT_ITEMS; ++j) val[j] = (u32)tile_base + woff + j * WAVE;
+    }
+    __syncthreads();
+
+    // 3. tile digit counts -> publish aggregate -> exclusive scan over digits
+    u32 count = 0, excl = 0;
+    if (tid < RADIX) {
+        u32 c = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const u32 t = s_whist[w * RADIX + tid];
+            s_whist[w * RADIX + tid] = c;   // exclusive over waves
+            c += t;
+        }
+        count = c;
+        __hip_atomic_store(&a.status[(u64)tile * RADIX + tid],
+                           pack_status(a.epoch, tile == first_tile ? FLAG_INCL : FLAG_AGG, count),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u32 incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        excl = incl - c;
+    }
+    __syncthreads();
+    if (tid < RADIX) {
+        for (int i = 0; i < wave; ++i) excl += s_wsum[i];
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) s_whist[w * RADIX + tid] += excl;   // tile-local start of (wave, digit)
+    }
+    __syncthreads();
+
+    // 4. keys -> LDS at their tile-local sorted position (needs only tile-local offsets; gives the
+    //    predecessor tiles time to publish before the look-back below)
+    u32 pos[SORT_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        pos[j] = wh[rd[j] >> 16] + (rd[j] & 0xFFFFu);
+        if (FULL || (woff + j * WAVE) < tile_n) s_keys[pos[j]] = key[j];
+    }
+    __syncthreads();   // keys are in LDS; s_whist is free from here on
+
+    // 5. look-back: exclusive prefix of this tile's digits over the predecessor tiles of its chunk;
+    //    meanwhile the other lanes clear the (chunk, next digit) histogram that reuses s_whist
+    const bool has_next = (a.next_shift >= 0) && !(ABL & 16);
+    if (has_next) for (int i = tid; i < NCHUNK * RADIX; i += BLOCK) s_whist[i] = 0;
+    if (tid < RADIX) {
+        u32 prefix = 0;
+        if (tile > first_tile && !(ABL & 1)) {
+            prefix = lookback_prefix(a.status, tile, first_tile, (u32)tid, a.epoch, a.dstat);
+            __hip_atomic_store(&a.status[(u64)tile * RADIX + tid], pack_status(a.epoch, FLAG_INCL, prefix + count),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // this digit's run occupies global positions [g0, g0 + count); gdelta maps tile-local -> global
+        const u32 g0 = a.digit_base[chunk * RADIX + tid] + prefix;
+        const u32 gdelta = g0 - excl;
+        // destination chunk of the run's records: c0, or c0 + 1 from tile-local position thr on
+        // (a run is at most one tile long and a chunk at least one tile, so one boundary at most)
+        const u32 c0 = chunk_of_tile(g0 >> a.g.tile_shift, a.g.tpc);
+        const u64 bnd = (u64)(c0 + 1) * a.g.tpc << a.g.tile_shift;   // first record of chunk c0 + 1
+        u32 thr = 0xFFFFu;
+        if (c0 + 1 < (u32)NCHUNK && bnd < (u64)g0 + count) thr = (u32)(bnd - gdelta);
+        s_tab[tid] = make_uint2(gdelta, (c0 << 16) | thr);
+    }
+    __syncthreads();
+
+    // 6. coalesced global stores per digit run (+ next pass's per-chunk histogram); the uniform
+    //    has_next decision is taken once so that the 16 LDS reads can be issued back to back
+    u32 gidx[SORT_ITEMS];
+    auto store_keys = [&](auto with_next) {
+        constexpr bool NEXT = decltype(with_next)::value;
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; ++k) {
+            const u32 p = k * BLOCK + tid;
+            if (FULL || p < tile_n) {
+                const u64 kk = s_keys[p];
+                const uint2 t = s_tab[digit_of(kk, a.shift, a.mask)];
+                gidx[k] = t.x + p;
+                if constexpr ((ABL & 8) != 0) gidx[k] = (u32)tile_base + p;
+                a.keys_out[gidx[k]] = kk;
+                if (NEXT) {
+                    const u32 dn = digit_of(kk, a.next_shift, a.next_mask);
+                    const u32 cn = (t.y >> 16) + (p >= (t.y & 0xFFFFu) ? 1u : 0u);
+                    atomicAdd(&s_whist[cn * RADIX + dn], 1u);
+                }
+            }
+        }
+    };
+    if (has_next) store_keys(std::true_type{}); else store_keys(std::false_type{});
+    sync_lds();   // LDS atomics above (see sync_lds); every read of s_keys is done
+    if (has_next) {
+        for (int i = tid; i < NCHUNK * RADIX; i += BLOCK) {
+            const u32 v = s_whist[i];
+            if (v) atomicAdd(&a.next_hist[i], v);
+        }
+    }
+    if constexpr ((ABL & 4) != 0) return;
+    u32* s_vals = reinterpret_cast<u32*>(s_keys);
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j)
+        if (FULL || (woff + j * WAVE) < tile_n) s_vals[pos[j]] = val[j];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; ++k) {
+        const u32 p = k * BLOCK + tid;
+        if (FULL || p < tile_n) a.vals_out[gidx[k]] = s_vals[p];
+    }
+}
+
 template <int BLOCK, int ABL = 0>
 __global__ __launch_bounds__(BLOCK, 4) void radix_onesweep_kernel(SortPassArgs a) {
     constexpr int WAVES = BLOCK / WAVE;
     constexpr int TILE = BLOCK * SORT_ITEMS;
     constexpr int WH = (WAVES * RADIX > NCHUNK * RADIX) ? WAVES * RADIX : NCHUNK * RADIX;
     static_assert(BLOCK >= RADIX, "one thread per digit in the scan / look-back phase");
+    static_assert(TILE < 0xFFFF, "tile-local positions must fit the 16-bit threshold field");
     __shared__ __attribute__((aligned(16))) u64 s_keys[TILE];  // reused as u32 values afterwards
-    __shared__ u32 s_whist[WH];   // per-wave digit counters; later the (chunk, next digit) histogram
-    __shared__ u32 s_dstart[RADIX];
-    __shared__ u32 s_gdelta[RADIX];
+    __shared__ u32 s_whist[WH];    // per-wave digit counters; later the (chunk, next digit) histogram
+    __shared__ uint2 s_tab[RADIX]; // per digit {global - local offset, base chunk << 16 | threshold}
     __shared__ u32 s_wsum[RADIX / WAVE];
-    __shared__ u32 s_tile;   // global tile index, or 0xFFFFFFFF = nothing left / abort
+    __shared__ u32 s_tile;   // global tile index, or 0xFFFFFFFF = nothing left
     __shared__ u32 s_chunk;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 n = a.g.n;
+    const int tid = threadIdx.x;
     if (tid == 0) {
         // One tile per workgroup.  Start at the chunk of this XCD; a chunk whose ticket has run past
         // its tile count is exhausted, move on to the next (ONE atomic per attempt, no pre-check:
@@ -252,153 +447,11 @@ __global__ __launch_bounds__(BLOCK, 4) void radix_onesweep_kernel(SortPassArgs a
     const u32 tile = s_tile;
     if (tile == 0xFFFFFFFFu) return;  // block-uniform
     const u32 chunk = s_chunk;
-    const u32 first_tile = chunk * a.g.tpc;
-    const u64 tile_base = (u64)tile * TILE;
-
-    // 1. load (wave-striped): wave w owns records [w*64*ITEMS, (w+1)*64*ITEMS) of the tile
-    u64 key[SORT_ITEMS];
-    u32 val[SORT_ITEMS];
-    const u64 wbase = tile_base + (u64)wave * (WAVE * SORT_ITEMS) + lane;
-#pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
-        const u64 p = wbase + (u64)j * WAVE;
-        key[j] = (p < n) ? a.keys_in[p] : ~0ull;
-    }
-
-    // 2. per-wave stable ranking with ballot match masks
-    u32 rank[SORT_ITEMS];
-    volatile u32* wh = s_whist + wave * RADIX;
-    const u64 lt = lanemask_lt();
-#pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
-        const bool valid = (wbase + (u64)j * WAVE) < n;
-        const u32 d = (u32)(key[j] >> a.shift) & a.mask;
-        u64 peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < RADIX_BITS; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const u64 m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        const u32 below = (u32)__popcll(peers & lt);
-        const u32 prior = valid ? wh[d] : 0u;
-        __builtin_amdgcn_wave_barrier();
-        if (valid && below == 0) wh[d] = prior + (u32)__popcll(peers);
-        __builtin_amdgcn_wave_barrier();
-        rank[j] = prior + below;
-    }
-    // values are fetched only now: their latency hides behind the count / look-back phase and
-    // they do not occupy registers during ranking
-    if (a.vals_in) {
-#pragma unroll
-        for (int j = 0; j < SORT_ITEMS; ++j) {
-            const u64 p = wbase + (u64)j * WAVE;
-            val[j] = (p < n) ? a.vals_in[p] : 0u;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < SORT_ITEMS; ++j) val[j] = (u32)(wbase + (u64)j * WAVE);
-    }
-    __syncthreads();
-
-    // 3. tile digit counts -> publish aggregate -> exclusive scan over digits
-    u32 count = 0, excl = 0;
-    if (tid < RADIX) {
-        u32 c = 0;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const u32 t = s_whist[w * RADIX + tid];
-            s_whist[w * RADIX + tid] = c;  // exclusive over waves
-            c += t;
-        }
-        count = c;
-        __hip_atomic_store(&a.status[(u64)tile * RADIX + tid],
-                           pack_status(a.epoch, tile == first_tile ? FLAG_INCL : FLAG_AGG, count),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        u32 incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const u32 t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
-        }
-        if (lane == 63) s_wsum[wave] = incl;
-        excl = incl - c;
-    }
-    __syncthreads();
-    if (tid < RADIX) {
-        u32 woff = 0;
-        for (int i = 0; i < wave; ++i) woff += s_wsum[i];
-        excl += woff;
-        s_dstart[tid] = excl;
-    }
-    __syncthreads();
-
-    // 4. keys -> LDS at their tile-local sorted position (needs only tile-local offsets; gives the
-    //    predecessor tiles time to publish before the look-back below)
-    u32 pos[SORT_ITEMS];
-#pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
-        const bool valid = (wbase + (u64)j * WAVE) < n;
-        const u32 d = (u32)(key[j] >> a.shift) & a.mask;
-        pos[j] = s_dstart[d] + s_whist[wave * RADIX + d] + rank[j];
-        if (valid) s_keys[pos[j]] = key[j];
-    }
-    __syncthreads();   // keys are in LDS; s_whist is free from here on
-
-    // 5. look-back: exclusive prefix of this tile's digits over the predecessor tiles of its chunk;
-    //    meanwhile the other lanes clear the (chunk, next digit) histogram that reuses s_whist
-    const bool has_next = (a.next_shift >= 0) && !(ABL & 16);
-    if (has_next) for (int i = tid; i < NCHUNK * RADIX; i += BLOCK) s_whist[i] = 0;
-    if (tid < RADIX) {
-        u32 prefix = 0;
-        if (tile > first_tile && !(ABL & 1)) {
-            prefix = lookback_prefix(a.status, tile, first_tile, (u32)tid, a.epoch, a.dstat);
-            __hip_atomic_store(&a.status[(u64)tile * RADIX + tid], pack_status(a.epoch, FLAG_INCL, prefix + count),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        s_gdelta[tid] = a.digit_base[chunk * RADIX + tid] + prefix - excl;
-    }
-    __syncthreads();
-
-    // 6. coalesced global stores per digit run (+ next pass's per-chunk histogram)
-    const u32 tile_n = (u32)((n - tile_base) < (u64)TILE ? (n - tile_base) : (u64)TILE);
-    u32 gidx[SORT_ITEMS];
-#pragma unroll
-    for (int k = 0; k < SORT_ITEMS; ++k) {
-        const u32 p = k * BLOCK + tid;
-        if (p < tile_n) {
-            const u64 kk = s_keys[p];
-            const u32 d = (u32)(kk >> a.shift) & a.mask;
-            gidx[k] = s_gdelta[d] + p;
-            if constexpr (ABL & 8) gidx[k] = (u32)tile_base + p;
-            a.keys_out[gidx[k]] = kk;
-            if (has_next) {
-                const u32 dn = (u32)(kk >> a.next_shift) & a.next_mask;
-                const u32 cn = chunk_of_tile(gidx[k] >> a.g.tile_shift, a.g.tpc);
-                atomicAdd(&s_whist[cn * RADIX + dn], 1u);
-            }
-        }
-    }
-    sync_lds();   // LDS atomics above (see sync_lds)
-    if (has_next) {
-        for (int i = tid; i < NCHUNK * RADIX; i += BLOCK) {
-            const u32 v = s_whist[i];
-            if (v) atomicAdd(&a.next_hist[i], v);
-        }
-    }
-    if constexpr (ABL & 4) return;
-    u32* s_vals = reinterpret_cast<u32*>(s_keys);
-#pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
-        const bool valid = (wbase + (u64)j * WAVE) < n;
-        if (valid) s_vals[pos[j]] = val[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < SORT_ITEMS; ++k) {
-        const u32 p = k * BLOCK + tid;
-        if (p < tile_n) a.vals_out[gidx[k]] = s_vals[p];
-    }
+    const u64 rest = (u64)a.g.n - (u64)tile * TILE;
+    if (rest >= (u64)TILE)
+        onesweep_tile<true, BLOCK, ABL>(a, tile, chunk, (u32)TILE, s_keys, s_whist, s_tab, s_wsum);
+    else
+        onesweep_tile<false, BLOCK, ABL>(a, tile, chunk, (u32)rest, s_keys, s_whist, s_tab, s_wsum);
 }
 
 // ---- host driver ----------------------------------------------------------------------------------

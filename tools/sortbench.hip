@@ -31,7 +31,44 @@ __global__ void copy4_kernel(const u32* __restrict__ a, u32* __restrict__ b, u64
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) b[i] = a[i];
 }
 
-template <int BLOCK, int ABL>
+// copy variants: what does the chip stream at, for the access shapes of the sort?
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void copy16u_kernel(const uint4* __restrict__ a_, uint4* __restrict__ b_, u64 n16) {
+    const v4u* __restrict__ a = reinterpret_cast<const v4u*>(a_);
+    v4u* __restrict__ b = reinterpret_cast<v4u*>(b_);
+    // each block owns a contiguous span of 256 * UNROLL uint4 per iteration
+    const u64 span = (u64)256 * UNROLL;
+    for (u64 base = (u64)blockIdx.x * span; base < n16; base += (u64)gridDim.x * span) {
+        v4u r[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const u64 i = base + (u64)u * 256 + threadIdx.x;
+            if (i < n16) r[u] = NT ? __builtin_nontemporal_load(&a[i]) : a[i];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const u64 i = base + (u64)u * 256 + threadIdx.x;
+            if (i < n16) { if (NT) __builtin_nontemporal_store(r[u], &b[i]); else b[i] = r[u]; }
+        }
+    }
+}
+// the sort's shape: 512 threads, one 8192-record tile per block, 8-byte key and 4-byte value accesses
+__global__ __launch_bounds__(512) void copy_tile_kernel(const u64* __restrict__ k, const u32* __restrict__ v, u64* __restrict__ ko,
+                                                        u32* __restrict__ vo, u32 n) {
+    const u64 base = (u64)blockIdx.x * 8192;
+    u64 kk[16]; u32 vv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const u64 i = base + j * 512 + threadIdx.x; kk[j] = i < n ? k[i] : 0; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const u64 i = base + j * 512 + threadIdx.x; vv[j] = i < n ? v[i] : 0; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const u64 i = base + j * 512 + threadIdx.x; if (i < n) ko[i] = kk[j]; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const u64 i = base + j * 512 + threadIdx.x; if (i < n) vo[i] = vv[j]; }
+}
+
+template <int BLOCK, int ABL, int VER = 1, int OPT = 0>
 float run_pass(RadixWorkspace& ws, hipStream_t st, u64* k0, u32* v0, u64* k1, u32* v1, u32 n, int shift, int reps, int home_mode = 0) {
     SortGeom g = make_geom(n, BLOCK * SORT_ITEMS);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -80,6 +117,20 @@ int main(int argc, char** argv) {
         }
         printf("n=2^%d  copy(12B/rec)            %8.3f ms  %7.1f GB/s\n", lg, best, gb / best * 1e3);
     }
+#define COPYV(name, ...) { hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); float best = 1e9f; \
+        for (int r = 0; r < 5; ++r) { CK(hipEventRecord(e0, st)); __VA_ARGS__; CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); \
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms; } \
+        printf("copy %-36s %8.3f ms  %7.1f GB/s\n", name, best, gb / best * 1e3); fflush(stdout); }
+    {
+        const u64 nk = (u64)n * 8 / 16, nv = (u64)n * 4 / 16;
+        COPYV("uint4 x1, grid 4096", (copy16u_kernel<1, false><<<4096, 256, 0, st>>>((const uint4*)k0, (uint4*)k1, nk), copy16u_kernel<1, false><<<4096, 256, 0, st>>>((const uint4*)v0, (uint4*)v1, nv)))
+        COPYV("uint4 x4, grid 2048", (copy16u_kernel<4, false><<<2048, 256, 0, st>>>((const uint4*)k0, (uint4*)k1, nk), copy16u_kernel<4, false><<<2048, 256, 0, st>>>((const uint4*)v0, (uint4*)v1, nv)))
+        COPYV("uint4 x8, grid 2048", (copy16u_kernel<8, false><<<2048, 256, 0, st>>>((const uint4*)k0, (uint4*)k1, nk), copy16u_kernel<8, false><<<2048, 256, 0, st>>>((const uint4*)v0, (uint4*)v1, nv)))
+        COPYV("uint4 x4 nt, grid 2048", (copy16u_kernel<4, true><<<2048, 256, 0, st>>>((const uint4*)k0, (uint4*)k1, nk), copy16u_kernel<4, true><<<2048, 256, 0, st>>>((const uint4*)v0, (uint4*)v1, nv)))
+        COPYV("uint4 x8 nt, grid 1024", (copy16u_kernel<8, true><<<1024, 256, 0, st>>>((const uint4*)k0, (uint4*)k1, nk), copy16u_kernel<8, true><<<1024, 256, 0, st>>>((const uint4*)v0, (uint4*)v1, nv)))
+        COPYV("uint4 x4, one span per block", (copy16u_kernel<4, false><<<(unsigned)((nk + 1023) / 1024), 256, 0, st>>>((const uint4*)k0, (uint4*)k1, nk), copy16u_kernel<4, false><<<(unsigned)((nv + 1023) / 1024), 256, 0, st>>>((const uint4*)v0, (uint4*)v1, nv)))
+        COPYV("tile shape (8 B + 4 B per lane)", (copy_tile_kernel<<<(n + 8191) / 8192, 512, 0, st>>>(k0, v0, k1, v1, n)))
+    }
     // calibration launches for the PMC counters (known byte counts at the kernel's access widths)
     copy8_kernel<<<4096, 256, 0, st>>>(k0, k1, (u64)n);
     copy4_kernel<<<4096, 256, 0, st>>>(v0, v1, (u64)n);
@@ -98,6 +149,26 @@ int main(int argc, char** argv) {
     RUN(512, 17, "no lookback, no next-hist")
     RUN(512, 8, "linear stores")
     RUN(512, 4, "no values")
+    RUN(512, 9, "linear stores, no lookback")
+    RUN(512, 25, "linear, no lb, no nh")
+    {   // correctness of the full pass: stable by digit, a permutation (values are iota), next-pass histogram
+        std::vector<u64> ka(n); std::vector<u32> va(n), ha(NCHUNK * RADIX);
+        CK(hipMemset(k1, 0, (size_t)n * 8)); CK(hipMemset(v1, 0xFF, (size_t)n * 4));
+        run_pass<512, 0>(ws, st, k0, v0, k1, v1, n, shift, 1);
+        CK(hipMemcpy(ka.data(), k1, (size_t)n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(va.data(), v1, (size_t)n * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(ha.data(), ws.hist(1), ha.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<u64> kin(n); CK(hipMemcpy(kin.data(), k0, (size_t)n * 8, hipMemcpyDeviceToHost));
+        size_t unsorted = 0, wrongkey = 0;
+        for (size_t i = 0; i < n; ++i) {
+            wrongkey += va[i] >= n || kin[va[i]] != ka[i];
+            if (i) { u32 da = (u32)(ka[i-1] >> shift) & 255u, db = (u32)(ka[i] >> shift) & 255u; unsorted += (da > db) || (da == db && va[i-1] >= va[i]); }
+        }
+        const SortGeom g = make_geom(n, 512 * SORT_ITEMS);
+        std::vector<u32> href(NCHUNK * RADIX, 0);
+        for (size_t i = 0; i < n; ++i) href[chunk_of_tile((u32)(i >> g.tile_shift), g.tpc) * RADIX + ((u32)(ka[i] >> (shift + 8)) & 255u)]++;
+        size_t hbad = 0; for (size_t i = 0; i < href.size(); ++i) hbad += href[i] != ha[i];
+        printf("check (512): %zu order violations, %zu records not matching their source, %zu next-histogram mismatches\n", unsorted, wrongkey, hbad);
+    }
 #define RUNH(B, A, H, name) { float ms = run_pass<B, A>(ws, st, k0, v0, k1, v1, n, shift, 4, H); \
         printf("block %d abl %2d home %d %-22s %8.3f ms  %7.1f GB/s\n", B, A, H, name, ms, gb / ms * 1e3); fflush(stdout); }
     RUNH(512, 17, 1, "no lb/nh, home=0")
