@@ -48,6 +48,9 @@ constexpr int NCHUNK = 8;         // look-back chains per pass = XCDs
 constexpr int SORT_ITEMS = 16;    // records per thread
 constexpr int MAX_PASSES = 8;
 constexpr u32 SPIN_LIMIT = 1u << 22;
+#ifndef SA_INCL_MASK
+#define SA_INCL_MASK 3u
+#endif
 #ifndef SA_LB_WINDOW
 #define SA_LB_WINDOW 4
 #endif
@@ -107,6 +110,7 @@ struct SortPassArgs {
     u32 epoch;
     DeviceStatus* dstat;
     int home_mode;          // 0: home chunk = XCC id (product); 1: chunk 0; 2: blockIdx & 7 (tools/sortbench.hip)
+    u32 incl_mask;          // a tile publishes its inclusive prefix only if (index in chunk & incl_mask) == incl_mask
 };
 
 // ---- pass-0 histogram: digit [shift, shift+8) per chunk of the INPUT order ---------------------------
@@ -351,8 +355,12 @@ __device__ __forceinline__ void onesweep_tile(const SortPassArgs& a, const u32 t
         u32 prefix = 0;
         if (tile > first_tile && !(ABL & 1)) {
             prefix = lookback_prefix(a.status, tile, first_tile, (u32)tid, a.epoch, a.dstat);
-            __hip_atomic_store(&a.status[(u64)tile * RADIX + tid], pack_status(a.epoch, FLAG_INCL, prefix + count),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // only every (incl_mask + 1)-th tile of a chunk publishes its inclusive prefix: a status store
+            // is a fabric write of its own per lane (8-byte write-through), and the successors' look-back
+            // is two to six tiles deep anyway (measured: every 4th tile 2.4-5.4 % faster than every tile)
+            if (((tile - first_tile) & a.incl_mask) == a.incl_mask)
+                __hip_atomic_store(&a.status[(u64)tile * RADIX + tid], pack_status(a.epoch, FLAG_INCL, prefix + count),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // this digit's run occupies global positions [g0, g0 + count); gdelta maps tile-local -> global
         const u32 g0 = a.digit_base[chunk * RADIX + tid] + prefix;
@@ -623,6 +631,7 @@ inline int radix_sort_pairs(RadixWorkspace& ws, hipStream_t stream, u64* keysA, 
         a.epoch = ws.epoch;
         a.dstat = ws.dstat;
         a.home_mode = 0;
+        a.incl_mask = SA_INCL_MASK;
         if ((rc = ws.timer.start(stream))) return rc;
         const u32 grid = pl.g.tiles;   // one tile per workgroup
         if (ws.block == 512)

@@ -154,10 +154,41 @@ __global__ __launch_bounds__(BLD_BLOCK) void keygen_kernel(const u8* __restrict_
 // lf[j]: bit0 = head (key differs from predecessor), bit1 = active (group of j has > 1 member).
 // Optional write-back of a refinement round: SA[apos[j]] = sidx[j]; gflags[apos[j]] |= head.
 // counts[tile] = {#active, #active heads} of the tile.
+// Optional bucket directory of the query path (first flags pass of a build only, dirargs.dir != nullptr):
+// dir[bkt] = first slot whose key has top-dbits >= bkt.  Slot j owns the buckets (top(K[j-1]), top(K[j])];
+// runs of up to DIR_INLINE buckets are written here, longer ones (unused codes of the compacted
+// alphabet leave holes of up to 2^dbits / 8 buckets) are queued for dir_fill_kernel.
+constexpr u32 DIR_INLINE = 8;
+struct DirArgs {
+    u32* dir;        // [2^dbits + 1], or nullptr
+    int dbits;
+    uint4* gaps;     // queue of {first bucket, last bucket, value, -}
+    u32* gap_count;  // zeroed by the host
+    u32 gap_cap;
+    DeviceStatus* dstat;
+};
+__device__ __forceinline__ void dir_emit(const DirArgs& d, u32 first, u32 last, u32 value) {
+    if (last - first < DIR_INLINE) {
+        for (u32 bkt = first; bkt <= last; ++bkt) d.dir[bkt] = value;
+    } else {
+        const u32 slot = atomicAdd(d.gap_count, 1u);
+        if (slot < d.gap_cap) d.gaps[slot] = make_uint4(first, last, value, 0u);
+        else __hip_atomic_store(&d.dstat->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // cannot happen: see gap_cap
+    }
+}
+
+__global__ __launch_bounds__(256) void dir_fill_kernel(DirArgs d) {
+    const u32 count = *d.gap_count < d.gap_cap ? *d.gap_count : d.gap_cap;
+    for (u32 e = blockIdx.x; e < count; e += gridDim.x) {
+        const uint4 g = d.gaps[e];
+        for (u64 bkt = (u64)g.x + threadIdx.x; bkt <= (u64)g.y; bkt += blockDim.x) d.dir[bkt] = g.z;
+    }
+}
+
 __global__ __launch_bounds__(BLD_BLOCK) void flags_kernel(const u64* __restrict__ keys, u32 n, u8* __restrict__ lf,
                                                           uint2* __restrict__ counts, const u32* __restrict__ apos,
                                                           const u32* __restrict__ sidx, u32* __restrict__ sa_out,
-                                                          u8* __restrict__ gflags) {
+                                                          u8* __restrict__ gflags, DirArgs dirargs) {
     __shared__ u32 s_a[BLD_BLOCK / WAVE], s_h[BLD_BLOCK / WAVE];
     const u64 base = (u64)blockIdx.x * BLD_TILE;
     u32 ca = 0, ch = 0;
@@ -166,8 +197,17 @@ __global__ __launch_bounds__(BLD_BLOCK) void flags_kernel(const u64* __restrict_
         const u64 j = base + (u64)it * BLD_BLOCK + threadIdx.x;
         if (j < n) {
             const u64 k = keys[j];
-            const bool head = (j == 0) || (keys[j - 1] != k);
+            const u64 kprev = (j == 0) ? 0ull : keys[j - 1];
+            const bool head = (j == 0) || (kprev != k);
             const bool next_head = (j + 1 == n) || (keys[j + 1] != k);
+            if (dirargs.dir && head) {
+                const int ds = 64 - dirargs.dbits;
+                const u32 bj = (u32)(k >> ds);
+                const u32 first = (j == 0) ? 0u : (u32)(kprev >> ds) + 1u;
+                if (first <= bj) dir_emit(dirargs, first, bj, (u32)j);
+            }
+            if (dirargs.dir && j + 1 == n)   // buckets above the last key, and the end marker dir[2^dbits]
+                dir_emit(dirargs, (u32)(k >> (64 - dirargs.dbits)) + 1u, 1u << dirargs.dbits, n);
             const bool act = !(head && next_head);
             lf[j] = (u8)((head ? 1 : 0) | (act ? 2 : 0));
             ca += act;
@@ -770,6 +810,7 @@ struct Builder {
     double pilot_dup_share = 0.0;     // share of sampled 8-byte windows seen before (pilot_kernel)
     DevBuf pilot;
     bool fuse_hist = true;            // SA_HIP_FUSE_HIST: digit histograms inside keygen
+    bool fuse_directory = true;       // SA_HIP_FUSE_DIR: query directory written by the first flags pass
     DevBuf partial, dbg, done;
     bool tiny_finisher = true;        // SA_HIP_TINY: direct-comparison finisher for groups of <= 8
     bool debug_rounds = false;
@@ -778,6 +819,7 @@ struct Builder {
     DevBuf qdir;
     CodeMap qmap;
     int q_b = 0, q_k0 = 0, q_dbits = 0;
+    bool dir_ready = false;   // the directory in qdir belongs to qkeys
 
     // Characters in the initial key.  Enough that, for an i.i.d. text with this byte
     // distribution, about 2 % of the suffixes still share their key (collision probability
@@ -817,6 +859,7 @@ struct Builder {
         if (const char* e = getenv("SA_HIP_INITIAL_CHARS")) initial_chars_override = atoi(e);
         if (const char* e = getenv("SA_HIP_CHUNK_ROUNDS")) chunk_rounds_before_doubling = atoi(e);
         if (const char* e = getenv("SA_HIP_FUSE_HIST")) fuse_hist = atoi(e) != 0;
+        if (const char* e = getenv("SA_HIP_FUSE_DIR")) fuse_directory = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_TINY")) tiny_finisher = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_DEBUG_ROUNDS")) debug_rounds = atoi(e) != 0;
         if (debug_rounds) { radix.debug_hook = &Builder::sort_debug_hook; radix.debug_ctx = this; }
@@ -922,10 +965,29 @@ struct Builder {
     }
 
     // head/active flags over `cnt` sorted keys (+ optional round write-back), scanned counts.
-    int flags_and_counts(const u64* keys, u32 cnt, u8* lf_out, const u32* apos, const u32* sidx, u32* totals_host) {
+    int flags_and_counts(const u64* keys, u32 cnt, u8* lf_out, const u32* apos, const u32* sidx, u32* totals_host,
+                         bool with_directory = false) {
         const u32 tiles = div_up(cnt, BLD_TILE);
+        DirArgs d{};
+        if (with_directory) {
+            // the directory of the query path comes out of this pass over the sorted keys for free
+            int rc = directory_layout(cnt);
+            if (rc) return rc;
+            d.dir = qdir.as<u32>();
+            d.dbits = q_dbits;
+            const u64 nb = (1ull << q_dbits) + 1;
+            d.gaps = reinterpret_cast<uint4*>(qdir.as<u8>() + dir_gap_offset(nb));
+            d.gap_cap = dir_gap_cap(nb);
+            d.gap_count = reinterpret_cast<u32*>(small.as<u8>() + 3584);
+            d.dstat = radix.dstat;
+            SA_HIP_CHECK(hipMemsetAsync(d.gap_count, 0, 4, stream));
+        }
         hipLaunchKernelGGL(flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, keys, cnt, lf_out, counts.as<uint2>(),
-                           apos, sidx, sa, flags.as<u8>());
+                           apos, sidx, sa, flags.as<u8>(), d);
+        if (with_directory) {
+            hipLaunchKernelGGL(dir_fill_kernel, dim3(1024), dim3(256), 0, stream, d);
+            dir_ready = true;
+        }
         return scan_counts(tiles, totals_host);
     }
 
@@ -965,20 +1027,33 @@ struct Builder {
     // levels: a 2^14-bucket directory by full binary searches, then the fine one inside its buckets.
     // Default q_dbits = log2(n) - 6 (about 64 slots per bucket: one more millisecond of build at
     // n = 1e9 buys 20 % on every query batch); SA_HIP_DIR_BITS overrides.
-    int build_directory() {
-        if (!qkeys || n < 2) { qkeys = nullptr; return 0; }
+    // qdir layout: fine directory u32[nb] | coarse directory u32[ncb] (two-level build only) | gap queue
+    static int dir_coarse_bits(int d) { return d > 16 ? 14 : 0; }
+    static size_t dir_gap_offset(u64 nb) { return (((size_t)nb + (1u << 14) + 1) * 4 + 15) & ~(size_t)15; }
+    // a queued run holds more than DIR_INLINE buckets and runs are disjoint, so nb / DIR_INLINE entries suffice
+    static u32 dir_gap_cap(u64 nb) { return (u32)(nb / DIR_INLINE + 2); }
+    int directory_layout(u64 count) {
         int lg = 0;
-        while ((1ull << lg) < n) ++lg;
+        while ((1ull << lg) < count) ++lg;
         int d = lg - 6;
         if (d < 8) d = 8;
         if (d > 24) d = 24;
         if (const char* e = getenv("SA_HIP_DIR_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 28) d = v; }
         q_dbits = d;
         const u64 nb = (1ull << d) + 1;
-        const int cbits = d > 16 ? 14 : 0;
-        const u64 ncb = cbits ? (1ull << cbits) + 1 : 0;
-        int rc = qdir.ensure((size_t)(nb + ncb) * 4);
+        return qdir.ensure(dir_gap_offset(nb) + (size_t)dir_gap_cap(nb) * sizeof(uint4));
+    }
+
+    // Directory by binary search (adopted indexes; a build gets it from its first flags pass)
+    int build_directory() {
+        if (!qkeys || n < 2) { qkeys = nullptr; return 0; }
+        if (dir_ready) return 0;
+        int rc = directory_layout(n);
         if (rc) return rc;
+        const int d = q_dbits;
+        const u64 nb = (1ull << d) + 1;
+        const int cbits = dir_coarse_bits(d);
+        const u64 ncb = cbits ? (1ull << cbits) + 1 : 0;
         u32* fine = qdir.as<u32>();
         u32* coarse = cbits ? fine + nb : nullptr;
         if (cbits)
@@ -992,6 +1067,7 @@ struct Builder {
     // Query structures for an adopted (text, SA): packed keys gathered from the text.
     int prepare_query_from_sa(const CodeMap& map, int b, u32 L) {
         qkeys = nullptr;
+        dir_ready = false;
         if (n < 2) return 0;
         const int k0 = choose_initial_chars(b, L);
         int rc = keys0.ensure((size_t)n * 8);
@@ -1042,6 +1118,7 @@ struct Builder {
         stats.bits_per_symbol = (u32)b;
         sa = vals0.as<u32>();
         qkeys = nullptr;
+        dir_ready = false;
         if (n == 0) return finish_stats();
         if (n == 1) {
             SA_HIP_CHECK(hipMemsetAsync(sa, 0, 4, stream));
@@ -1068,7 +1145,7 @@ struct Builder {
 
         // head flags, active counts
         u32 tot[2];
-        if ((rc = flags_and_counts(kres, n32, flags.as<u8>(), nullptr, nullptr, tot))) return rc;
+        if ((rc = flags_and_counts(kres, n32, flags.as<u8>(), nullptr, nullptr, tot, fuse_directory))) return rc;
         if ((rc = check_device_status())) return rc;
         u32 M = tot[0], G = tot[1];
         u64 h = (u64)k0;

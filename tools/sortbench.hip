@@ -69,7 +69,7 @@ __global__ __launch_bounds__(512) void copy_tile_kernel(const u64* __restrict__ 
 }
 
 template <int BLOCK, int ABL, int VER = 1, int OPT = 0>
-float run_pass(RadixWorkspace& ws, hipStream_t st, u64* k0, u32* v0, u64* k1, u32* v1, u32 n, int shift, int reps, int home_mode = 0) {
+float run_pass(RadixWorkspace& ws, hipStream_t st, u64* k0, u32* v0, u64* k1, u32* v1, u32 n, int shift, int reps, int home_mode = 0, u32 incl_mask = SA_INCL_MASK) {
     SortGeom g = make_geom(n, BLOCK * SORT_ITEMS);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e9f;
@@ -81,7 +81,7 @@ float run_pass(RadixWorkspace& ws, hipStream_t st, u64* k0, u32* v0, u64* k1, u3
         SortPassArgs a;
         a.keys_in = k0; a.vals_in = v0; a.keys_out = k1; a.vals_out = v1; a.g = g; a.shift = shift; a.mask = 255u;
         a.next_shift = shift + 8; a.next_mask = 255u; a.next_hist = ws.hist(1);
-        a.digit_base = ws.base(); a.status = ws.status; a.ticket = ws.tickets(); a.epoch = ++ws.epoch; a.dstat = ws.dstat; a.home_mode = home_mode;
+        a.digit_base = ws.base(); a.status = ws.status; a.ticket = ws.tickets(); a.epoch = ++ws.epoch; a.dstat = ws.dstat; a.home_mode = home_mode; a.incl_mask = incl_mask;
         CK(hipEventRecord(e0, st));
         hipLaunchKernelGGL((radix_onesweep_kernel<BLOCK, ABL>), dim3(g.tiles), dim3(BLOCK), 0, st, a);
         CK(hipEventRecord(e1, st));
@@ -149,6 +149,13 @@ int main(int argc, char** argv) {
     RUN(512, 17, "no lookback, no next-hist")
     RUN(512, 8, "linear stores")
     RUN(512, 4, "no values")
+#define RUNI(M, name) { float ms = run_pass<512, 0>(ws, st, k0, v0, k1, v1, n, shift, 4, 0, M); \
+        printf("block 512 incl_mask %d %-24s %8.3f ms  %7.1f GB/s\n", M, name, ms, gb / ms * 1e3); fflush(stdout); }
+    RUNI(0, "INCL every tile")
+    RUNI(1, "INCL every 2nd tile")
+    RUNI(3, "INCL every 4th tile")
+    RUNI(7, "INCL every 8th tile")
+    RUNI(0, "INCL every tile")
     RUN(512, 9, "linear stores, no lookback")
     RUN(512, 25, "linear, no lb, no nh")
     {   // correctness of the full pass: stable by digit, a permutation (values are iota), next-pass histogram
