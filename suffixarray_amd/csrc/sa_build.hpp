@@ -38,10 +38,16 @@ struct CodeMap {
 };
 
 // ---- byte histogram (libsais `freq`, libsais.c:1363-1371) -------------------------------------
+// Small alphabets put many lanes of a wave on the same counter (LDS atomics to one address serialise),
+// so the histogram is kept in HIST_COPIES copies selected by the lane: 27 symbols x 8 copies leave
+// about one lane per address and instruction.
+constexpr int HIST_COPIES = 8;
 __global__ __launch_bounds__(256) void byte_hist_kernel(const u8* __restrict__ text, u64 n, u64* __restrict__ hist) {
-    __shared__ u32 s_h[256];
-    s_h[threadIdx.x] = 0;
+    constexpr int CS = 257;   // copy stride: the same symbol in different copies falls into different banks
+    __shared__ u32 s_h[HIST_COPIES * CS];
+    for (int i = threadIdx.x; i < HIST_COPIES * CS; i += 256) s_h[i] = 0;
     __syncthreads();
+    u32* my = s_h + (threadIdx.x & (HIST_COPIES - 1)) * CS;
     const u64 nvec = n / 16;
     const uint4* v = reinterpret_cast<const uint4*>(text);
     const u64 stride = (u64)gridDim.x * blockDim.x;
@@ -50,17 +56,19 @@ __global__ __launch_bounds__(256) void byte_hist_kernel(const u8* __restrict__ t
         const u32 w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            atomicAdd(&s_h[w[k] & 255u], 1u);
-            atomicAdd(&s_h[(w[k] >> 8) & 255u], 1u);
-            atomicAdd(&s_h[(w[k] >> 16) & 255u], 1u);
-            atomicAdd(&s_h[w[k] >> 24], 1u);
+            atomicAdd(&my[w[k] & 255u], 1u);
+            atomicAdd(&my[(w[k] >> 8) & 255u], 1u);
+            atomicAdd(&my[(w[k] >> 16) & 255u], 1u);
+            atomicAdd(&my[w[k] >> 24], 1u);
         }
     }
     if (blockIdx.x == 0) {
-        for (u64 i = nvec * 16 + threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_h[text[i]], 1u);
+        for (u64 i = nvec * 16 + threadIdx.x; i < n; i += blockDim.x) atomicAdd(&my[text[i]], 1u);
     }
     sync_lds();   // LDS atomics above (see sync_lds)
-    const u32 c = s_h[threadIdx.x];
+    u32 c = 0;
+#pragma unroll
+    for (int k = 0; k < HIST_COPIES; ++k) c += s_h[k * CS + threadIdx.x];
     if (c) atomicAdd((unsigned long long*)&hist[threadIdx.x], (unsigned long long)c);
 }
 
@@ -175,6 +183,18 @@ __device__ __forceinline__ void dir_emit(const DirArgs& d, u32 first, u32 last, 
         if (slot < d.gap_cap) d.gaps[slot] = make_uint4(first, last, value, 0u);
         else __hip_atomic_store(&d.dstat->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // cannot happen: see gap_cap
     }
+}
+
+// The directory is written early in the build; reading it once at the end leaves its 2^dbits * 4 bytes
+// (<= 64 MB) in the memory-side cache for the first query batch, as a directory built last would be.
+__global__ __launch_bounds__(256) void dir_touch_kernel(const uint4* __restrict__ dir16, u64 n16, u32* __restrict__ sink) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 acc = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const uint4 v = dir16[i];
+        acc |= v.x & v.y & v.z & v.w;
+    }
+    if (acc == 0xFFFFFFFFu) *sink = acc;   // slots are < n <= 2^32 - 2: never taken, keeps the loads alive
 }
 
 __global__ __launch_bounds__(256) void dir_fill_kernel(DirArgs d) {
@@ -1047,7 +1067,12 @@ struct Builder {
     // Directory by binary search (adopted indexes; a build gets it from its first flags pass)
     int build_directory() {
         if (!qkeys || n < 2) { qkeys = nullptr; return 0; }
-        if (dir_ready) return 0;
+        if (dir_ready) {
+            const u64 n16 = ((1ull << q_dbits) + 1) / 4;
+            hipLaunchKernelGGL(dir_touch_kernel, dim3(stream_grid(n16, 256)), dim3(256), 0, stream, qdir.as<uint4>(), n16,
+                               reinterpret_cast<u32*>(small.as<u8>() + 3588));
+            return 0;
+        }
         int rc = directory_layout(n);
         if (rc) return rc;
         const int d = q_dbits;

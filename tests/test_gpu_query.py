@@ -205,3 +205,29 @@ def test_api_edge_cases(gpu):
             idx.sa_range(5, 100)
         assert idx.sa_range(0, 0).size == 0
         assert b"no index" not in lib.sa_hip_last_error() or True
+
+
+def test_directory_from_flags_pass_matches_searched_directory(gpu, oracle, monkeypatch):
+    """The bucket directory written by the first flags pass of a build (runs of buckets between
+    consecutive keys; long runs queued for dir_fill_kernel) against the directory built by binary
+    search (SA_HIP_FUSE_DIR=0) and against the oracle, on alphabets that leave large holes in the key space."""
+    rng = np.random.default_rng(77)
+    texts = {
+        "two_far_bytes": rng.choice(np.array([1, 254], dtype=np.uint8), 300_000),
+        "sparse_5": rng.choice(np.array([3, 9, 10, 200, 255], dtype=np.uint8), 200_000),
+        "uniform27": rng.integers(97, 124, 1_000_000).astype(np.uint8),
+        "one_symbol_run_then_noise": np.concatenate([np.full(50_000, 120, np.uint8), rng.integers(97, 100, 50_000).astype(np.uint8)]),
+        "tiny": np.frombuffer(b"abracadabra", dtype=np.uint8).copy(),
+    }
+    for name, t in texts.items():
+        pats = cases.query_patterns(t, 400, rng)
+        got = {}
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("SA_HIP_FUSE_DIR", fuse)
+            with gpu.DeviceIndex(t.size, 0) as idx:
+                idx.build(t, 0)
+                got[fuse] = idx.query_batch(pats)
+        assert np.array_equal(got["1"], got["0"]), name
+        if t.size <= 300_000:
+            sa = oracle.sais(t).astype(np.uint32)
+            assert np.array_equal(got["1"], oracle.query_batch(t, sa, 0xFFFFFFFF, pats)), name
