@@ -44,15 +44,19 @@ def usable_cpus():
     return n
 
 
-def pmc_traffic(n, launches_per_step):
+PASS_KERNELS = ["radix_onesweep_kernel<512, 0, false>", "radix_onesweep_kernel<512, 0, true>",
+                "seg_onesweep_kernel<512, false>", "seg_onesweep_kernel<512, true>"]   # sa_hip_build_stats.pass_*
+
+
+def pmc_traffic(n, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc run
     (profiles/pmc_onesweep.json; PMC passes cannot run inside this process).  Only reported for
-    the workload it was measured on."""
+    the workload and the kernel it was measured on."""
     try:
         j = json.load(open(os.path.join(ROOT, "profiles", "pmc_onesweep.json")))
     except Exception:
         return None
-    if n != 1_000_000_000 or launches_per_step != j.get("launches_per_build"):
+    if n != 1_000_000_000 or j.get("kernel") != kernel:
         return None
     return j["traffic_bytes_per_launch"]
 
@@ -152,6 +156,7 @@ def main():
         step()
     barrier()
     build_ms, radix_ms, radix_launches, radix_bytes, query_ms = 0.0, 0.0, 0, 0, 0.0
+    kind_ms, kind_bytes, kind_launches = [0.0] * 4, [0] * 4, [0] * 4
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -160,6 +165,8 @@ def main():
         radix_ms += st["radix_ms"]
         radix_launches += st["radix_passes"]
         radix_bytes += st["radix_bytes"]
+        for k in range(4):
+            kind_ms[k] += st["pass_ms"][k]; kind_bytes[k] += st["pass_bytes"][k]; kind_launches[k] += st["pass_launches"][k]
         query_ms += idx.query_stats()["kernel_ms"]
     barrier()
     dt = time.perf_counter() - t0
@@ -215,9 +222,12 @@ def main():
         steps = args.steps
         chars_per_s = world * N * steps / (build_ms_max / 1e3)          # replicas: every rank builds N chars
         queries_per_s = world * Q * steps / (query_ms_max / 1e3)
-        pass_ms = radix_ms / max(radix_launches, 1)
-        bytes_per_launch = radix_bytes / max(radix_launches, 1)
-        achieved = radix_bytes / (radix_ms / 1e3) if radix_ms > 0 else 0.0
+        # dominant kernel = the sort-pass kernel with the largest share of the timed region
+        dom = max(range(4), key=lambda k: kind_ms[k])
+        pass_ms = kind_ms[dom] / max(kind_launches[dom], 1)
+        bytes_per_launch = kind_bytes[dom] / max(kind_launches[dom], 1)
+        achieved = kind_bytes[dom] / (kind_ms[dom] / 1e3) if kind_ms[dom] > 0 else 0.0
+        all_achieved = radix_bytes / (radix_ms / 1e3) if radix_ms > 0 else 0.0
         bq = 2 * int(np.ceil(np.log2(max(N, 2)))) * (4 + m)              # reference bytes per query
         q_achieved = Q * steps * bq / (query_ms / 1e3) if query_ms > 0 else 0.0
         line = {
@@ -243,11 +253,16 @@ def main():
             "replica_query_ok": replica_ok,
             "build_stats": {k: last[k] for k in ("sigma", "bits_per_symbol", "initial_chars", "rounds", "chunk_rounds",
                                                  "doubling_rounds", "final_depth", "radix_passes", "active_total")},
-            "roofline": {"bound": "hbm", "kernel": "radix_onesweep_kernel", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+            "roofline": {"bound": "hbm", "kernel": PASS_KERNELS[dom], "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                         "traffic": pmc_traffic(N, radix_launches // max(steps, 1)),
+                         "traffic": pmc_traffic(N, PASS_KERNELS[dom]),
                          "traffic_note": "bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE on this workload, profiles/pmc_onesweep.json",
-                         "launches": radix_launches, "avg_launch_ms": pass_ms, "bytes_per_launch": bytes_per_launch},
+                         "launches": kind_launches[dom], "avg_launch_ms": pass_ms, "bytes_per_launch": bytes_per_launch},
+            "sort_passes": {"achieved": all_achieved / 1e9, "unit": "GB/s", "frac": all_achieved / HBM_PEAK, "launches": radix_launches,
+                            "by_kernel": {PASS_KERNELS[k]: {"launches": kind_launches[k], "avg_launch_ms": kind_ms[k] / kind_launches[k],
+                                                            "bytes_per_launch": kind_bytes[k] / kind_launches[k],
+                                                            "achieved": kind_bytes[k] / kind_ms[k] / 1e6}
+                                          for k in range(4) if kind_launches[k]}},
             "roofline_query": {"bound": "hbm", "kernel": "query_kernel", "achieved": q_achieved / 1e9, "peak": HBM_PEAK / 1e9,
                                "unit": "GB/s", "frac": q_achieved / HBM_PEAK, "bytes_per_query_model": bq},
             "gate": gate,

@@ -158,11 +158,18 @@ typedef struct sa_hip_build_stats {
     uint32_t final_depth;        /* h when the active set became empty                     */
     uint32_t radix_passes;       /* onesweep launches over all sorts                       */
     uint64_t radix_records;      /* sum over passes of records moved                       */
-    uint64_t radix_bytes;        /* algorithmic bytes of those passes: 2*M*(8+4) each      */
+    uint64_t radix_bytes;        /* algorithmic bytes of those passes (read + written)    */
     uint64_t active_total;       /* sum over rounds of active-set sizes                    */
     uint64_t tiny_resolved;      /* suffixes ordered by the tiny-group finisher            */
     double   radix_ms;           /* HIP-event time of all onesweep launches                */
     double   total_ms;           /* HIP-event time of the whole device build               */
+    /* the sort passes by kernel: [0] radix_onesweep_kernel<512> (u64 key + u32 value in and out),
+     * [1] the same with narrow output (top digit of a narrow sort: u32 key + u32 value out),
+     * [2] seg_onesweep_kernel<512,false> (u32 key + u32 value in and out),
+     * [3] seg_onesweep_kernel<512,true> (u32 key + u32 value in, u64 key + u32 value out) */
+    double   pass_ms[4];
+    uint64_t pass_bytes[4];      /* algorithmic bytes (read + written)                      */
+    uint32_t pass_launches[4];
 } sa_hip_build_stats;
 int sa_hip_index_build_stats(const sa_hip_index* idx, sa_hip_build_stats* out);
 

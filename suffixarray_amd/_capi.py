@@ -46,10 +46,11 @@ class BuildStats(C.Structure):
                 ("doubling_rounds", C.c_uint32), ("final_depth", C.c_uint32), ("radix_passes", C.c_uint32),
                 ("radix_records", C.c_uint64), ("radix_bytes", C.c_uint64), ("active_total", C.c_uint64),
                 ("tiny_resolved", C.c_uint64),
-                ("radix_ms", C.c_double), ("total_ms", C.c_double)]
+                ("radix_ms", C.c_double), ("total_ms", C.c_double),
+                ("pass_ms", C.c_double * 4), ("pass_bytes", C.c_uint64 * 4), ("pass_launches", C.c_uint32 * 4)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if k.startswith("pass_") else getattr(self, k)) for k, _ in self._fields_}
 
 
 class CsvColumn(C.Structure):

@@ -110,6 +110,8 @@ struct SortPassArgs {
     u32 epoch;
     DeviceStatus* dstat;
     int home_mode;          // 0: home chunk = XCC id (product); 1: chunk 0; 2: blockIdx & 7 (tools/sortbench.hip)
+    u32* keys_out32;        // NARROW kernels: the key leaves as (u32)(key >> narrow_shift) (radix_narrow.hpp)
+    int narrow_shift;
     u32 incl_mask;          // a tile publishes its inclusive prefix only if (index in chunk & incl_mask) == incl_mask
 };
 
@@ -232,9 +234,54 @@ __device__ __forceinline__ u32 lookback_prefix(const u64* __restrict__ status, u
 // ABL: ablation mask for tools/sortbench.hip only (0 in the product): 1 = no look-back (every tile
 // of a chunk then writes to the same place: the stores stay in cache, NOT a bandwidth figure),
 // 4 = no values, 8 = stores not scattered (streaming copy), 16 = no next-pass histogram.
+// Per-wave stable ranking of SORT_ITEMS wave-striped records by one digit: rd[j] = (number of records of
+// this wave with the same digit that precede record j in memory order) | digit << 16; wh[digit] ends as
+// the wave's digit count.  Two records at a time (two independent instruction streams); per digit bit
+// ONE v_bfe_i32 (e = -bit), ONE v_cmp (the ballot) and one three-input bit operation per 32-bit half of
+// the peer mask.  The empty asm statements keep the compiler from re-associating the mask updates into
+// longer chains of two-input operations.
+template <bool FULL, typename KeyT>
+__device__ __forceinline__ void wave_rank(const KeyT (&key)[SORT_ITEMS], int shift, u32 mask, u32 woff, u32 tile_n,
+                                          u32* wh, u32 (&rd)[SORT_ITEMS]) {
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j += 2) {
+        bool valid[2];
+        u32 d[2], lo[2], hi[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            valid[i] = FULL || (woff + (j + i) * WAVE) < tile_n;
+            d[i] = (u32)(key[j + i] >> shift) & mask;
+            lo[i] = ~0u; hi[i] = ~0u;
+            if (!FULL) { const u64 vm = __ballot(valid[i]); lo[i] = (u32)vm; hi[i] = (u32)(vm >> 32); }
+        }
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; ++b) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                u32 e = (u32)__builtin_amdgcn_sbfe((int)d[i], b, 1);   // all ones where the bit is set
+                asm("" : "+v"(e));
+                const u64 m = __ballot(e != 0);
+                lo[i] &= ~((u32)m ^ e);
+                hi[i] &= ~((u32)(m >> 32) ^ e);
+                asm("" : "+v"(lo[i]), "+v"(hi[i]));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const u32 below = __builtin_amdgcn_mbcnt_hi(hi[i], __builtin_amdgcn_mbcnt_lo(lo[i], 0u));
+            const u32 total = (u32)__popc(lo[i]) + (u32)__popc(hi[i]);
+            const u32 prior = wh[d[i]];
+            __builtin_amdgcn_wave_barrier();
+            if (valid[i] && below == 0) wh[d[i]] = prior + total;
+            __builtin_amdgcn_wave_barrier();
+            rd[j + i] = (prior + below) | (d[i] << 16);
+        }
+    }
+}
+
 __device__ __forceinline__ u32 digit_of(u64 key, int shift, u32 mask) { return (u32)(key >> shift) & mask; }
 
-template <bool FULL, int BLOCK, int ABL>
+template <bool FULL, int BLOCK, int ABL, bool NARROW>
 __device__ __forceinline__ void onesweep_tile(const SortPassArgs& a, const u32 tile, const u32 chunk, const u32 tile_n,
                                               u64* s_keys, u32* s_whist, uint2* s_tab, u32* s_wsum) {
     constexpr int WAVES = BLOCK / WAVE;
@@ -253,43 +300,10 @@ __device__ __forceinline__ void onesweep_tile(const SortPassArgs& a, const u32 t
         key[j] = (FULL || p < tile_n) ? kin[p] : ~0ull;
     }
 
-    // 2. per-wave stable ranking with ballot match masks, two records at a time
+    // 2. per-wave stable ranking with ballot match masks
     u32 rd[SORT_ITEMS];   // rank within (wave, digit) | digit << 16
     u32* wh = s_whist + wave * RADIX;
-#pragma unroll
-    for (int j = 0; j < SORT_ITEMS; j += 2) {
-        bool valid[2];
-        u32 d[2], lo[2], hi[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            valid[i] = FULL || (woff + (j + i) * WAVE) < tile_n;
-            d[i] = digit_of(key[j + i], a.shift, a.mask);
-            lo[i] = ~0u; hi[i] = ~0u;
-            if (!FULL) { const u64 vm = __ballot(valid[i]); lo[i] = (u32)vm; hi[i] = (u32)(vm >> 32); }
-        }
-#pragma unroll
-        for (int b = 0; b < RADIX_BITS; ++b) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                u32 e = (u32)__builtin_amdgcn_sbfe((int)d[i], b, 1);   // all ones where the bit is set
-                asm("" : "+v"(e));       // keep e, the compare on it and the two bit operations as written
-                const u64 m = __ballot(e != 0);
-                lo[i] &= ~((u32)m ^ e);
-                hi[i] &= ~((u32)(m >> 32) ^ e);
-                asm("" : "+v"(lo[i]), "+v"(hi[i]));
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const u32 below = __builtin_amdgcn_mbcnt_hi(hi[i], __builtin_amdgcn_mbcnt_lo(lo[i], 0u));
-            const u32 total = (u32)__popc(lo[i]) + (u32)__popc(hi[i]);
-            const u32 prior = wh[d[i]];
-            __builtin_amdgcn_wave_barrier();
-            if (valid[i] && below == 0) wh[d[i]] = prior + total;
-            __builtin_amdgcn_wave_barrier();
-            rd[j + i] = (prior + below) | (d[i] << 16);
-        }
-    }
+    wave_rank<FULL>(key, a.shift, a.mask, woff, tile_n, wh, rd);
     // values are fetched only now: their latency hides behind the count / look-back phase and
     // they do not occupy registers during ranking
     u32 val[SORT_ITEMS];
@@ -388,7 +402,8 @@ __device__ __forceinline__ void onesweep_tile(const SortPassArgs& a, const u32 t
                 const uint2 t = s_tab[digit_of(kk, a.shift, a.mask)];
                 gidx[k] = t.x + p;
                 if constexpr ((ABL & 8) != 0) gidx[k] = (u32)tile_base + p;
-                a.keys_out[gidx[k]] = kk;
+                if (NARROW) a.keys_out32[gidx[k]] = (u32)(kk >> a.narrow_shift);
+                else a.keys_out[gidx[k]] = kk;
                 if (NEXT) {
                     const u32 dn = digit_of(kk, a.next_shift, a.next_mask);
                     const u32 cn = (t.y >> 16) + (p >= (t.y & 0xFFFFu) ? 1u : 0u);
@@ -418,7 +433,7 @@ __device__ __forceinline__ void onesweep_tile(const SortPassArgs& a, const u32 t
     }
 }
 
-template <int BLOCK, int ABL = 0>
+template <int BLOCK, int ABL = 0, bool NARROW = false>
 __global__ __launch_bounds__(BLOCK, 4) void radix_onesweep_kernel(SortPassArgs a) {
     constexpr int WAVES = BLOCK / WAVE;
     constexpr int TILE = BLOCK * SORT_ITEMS;
@@ -457,21 +472,30 @@ __global__ __launch_bounds__(BLOCK, 4) void radix_onesweep_kernel(SortPassArgs a
     const u32 chunk = s_chunk;
     const u64 rest = (u64)a.g.n - (u64)tile * TILE;
     if (rest >= (u64)TILE)
-        onesweep_tile<true, BLOCK, ABL>(a, tile, chunk, (u32)TILE, s_keys, s_whist, s_tab, s_wsum);
+        onesweep_tile<true, BLOCK, ABL, NARROW>(a, tile, chunk, (u32)TILE, s_keys, s_whist, s_tab, s_wsum);
     else
-        onesweep_tile<false, BLOCK, ABL>(a, tile, chunk, (u32)rest, s_keys, s_whist, s_tab, s_wsum);
+        onesweep_tile<false, BLOCK, ABL, NARROW>(a, tile, chunk, (u32)rest, s_keys, s_whist, s_tab, s_wsum);
 }
 
 // ---- host driver ----------------------------------------------------------------------------------
 
-// HIP-event stopwatch for one class of launches (accumulated per build / per batch).
+// HIP-event stopwatch for the sort passes of a build, by kernel:
+//   0 radix_onesweep_kernel<512>            (u64 key, u32 value in and out)
+//   1 radix_onesweep_kernel<512, 0, true>   (top digit of a narrow sort: u64 key in, u32 key + u32 value out)
+//   2 seg_onesweep_kernel<512, false>       (u32 key, u32 value in and out)
+//   3 seg_onesweep_kernel<512, true>        (u32 key, u32 value in; u64 key, u32 value out)
+constexpr int PASS_KINDS = 4;
 struct EventTimer {
     static constexpr int CAP = 128;
     hipEvent_t ev[2 * CAP];
+    int kind_of[CAP];
     int used = 0;
     bool ready = false;
     double total_ms = 0.0;
     u64 launches = 0;
+    double kind_ms[PASS_KINDS] = {0, 0, 0, 0};
+    u64 kind_launches[PASS_KINDS] = {0, 0, 0, 0};
+    u64 kind_bytes[PASS_KINDS] = {0, 0, 0, 0};
 
     int init() {
         for (int i = 0; i < 2 * CAP; ++i) SA_HIP_CHECK(hipEventCreate(&ev[i]));
@@ -483,24 +507,32 @@ struct EventTimer {
         for (int i = 0; i < 2 * CAP; ++i) (void)hipEventDestroy(ev[i]);
         ready = false;
     }
-    void reset() { used = 0; total_ms = 0.0; launches = 0; }
+    void reset() {
+        used = 0; total_ms = 0.0; launches = 0;
+        for (int k = 0; k < PASS_KINDS; ++k) { kind_ms[k] = 0.0; kind_launches[k] = 0; kind_bytes[k] = 0; }
+    }
     int flush() {
         for (int i = 0; i < used; ++i) {
             SA_HIP_CHECK(hipEventSynchronize(ev[2 * i + 1]));
             float ms = 0.f;
             SA_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
             total_ms += ms;
+            kind_ms[kind_of[i]] += ms;
         }
         used = 0;
         return 0;
     }
-    int start(hipStream_t s) {
+    int start(hipStream_t s, int kind = 0) {
         if (used == CAP) { int rc = flush(); if (rc) return rc; }
+        kind_of[used] = kind;
         SA_HIP_CHECK(hipEventRecord(ev[2 * used], s));
         return 0;
     }
-    int stop(hipStream_t s) {
+    // bytes: algorithmic bytes of the launch (records x bytes read + written per record)
+    int stop(hipStream_t s, u64 bytes = 0) {
         SA_HIP_CHECK(hipEventRecord(ev[2 * used + 1], s));
+        kind_launches[kind_of[used]] += 1;
+        kind_bytes[kind_of[used]] += bytes;
         ++used;
         ++launches;
         return 0;
@@ -516,6 +548,7 @@ struct RadixWorkspace {
     int block = 512;           // workgroup size of the pass kernel (tile = block * SORT_ITEMS)
     EventTimer timer;          // onesweep launches only
     u64 pass_records = 0;      // sum over passes of records moved
+    u64 pass_bytes = 0;        // sum over passes of algorithmic bytes (records x bytes read + written per record)
     u64 passes = 0;
     // debugging aid: called after every pass with the pass's output (SA_HIP_DEBUG_ROUNDS)
     void (*debug_hook)(void* ctx, int pass, int npasses, int shift, u32 mask, const u64* kin, const u32* vin,
@@ -555,7 +588,7 @@ struct RadixWorkspace {
         status = nullptr; small = nullptr; dstat = nullptr;
         timer.destroy();
     }
-    void reset_stats() { timer.reset(); pass_records = 0; passes = 0; }
+    void reset_stats() { timer.reset(); pass_records = 0; pass_bytes = 0; passes = 0; }
 };
 
 struct SortPlan {
@@ -632,14 +665,18 @@ inline int radix_sort_pairs(RadixWorkspace& ws, hipStream_t stream, u64* keysA, 
         a.dstat = ws.dstat;
         a.home_mode = 0;
         a.incl_mask = SA_INCL_MASK;
-        if ((rc = ws.timer.start(stream))) return rc;
+        a.keys_out32 = nullptr;
+        a.narrow_shift = 0;
+        if ((rc = ws.timer.start(stream, 0))) return rc;
         const u32 grid = pl.g.tiles;   // one tile per workgroup
         if (ws.block == 512)
             hipLaunchKernelGGL((radix_onesweep_kernel<512, 0>), dim3(grid), dim3(512), 0, stream, a);
         else
             hipLaunchKernelGGL((radix_onesweep_kernel<256, 0>), dim3(grid), dim3(256), 0, stream, a);
-        if ((rc = ws.timer.stop(stream))) return rc;
+        const u64 pass_b = (u64)n * (a.vals_in ? 24u : 20u);   // pass 0 of a build generates its values
+        if ((rc = ws.timer.stop(stream, pass_b))) return rc;
         ws.pass_records += n;
+        ws.pass_bytes += pass_b;
         ws.passes += 1;
         if (ws.debug_hook) ws.debug_hook(ws.debug_ctx, p, pl.npasses, a.shift, a.mask, kin, a.vals_in, kout, vout, n);
         u64* tk = kin; kin = kout; kout = tk;

@@ -23,7 +23,7 @@
 #include <vector>
 
 #include "common.hpp"
-#include "radix_sort.hpp"
+#include "radix_narrow.hpp"
 
 namespace sa {
 
@@ -818,6 +818,7 @@ struct Builder {
     // round pool
     DevBuf apos0, apos1, aidx, gid, rkeys0, rkeys1, ridx0, ridx1, lf, tile_last, carry;
     RadixWorkspace radix;
+    NarrowWorkspace narrow;
     u32* sa = nullptr;        // points into vals0/vals1 after a build (or into sa_own after load)
     DevBuf sa_own;
     u64 n = 0;
@@ -831,6 +832,7 @@ struct Builder {
     DevBuf pilot;
     bool fuse_hist = true;            // SA_HIP_FUSE_HIST: digit histograms inside keygen
     bool fuse_directory = true;       // SA_HIP_FUSE_DIR: query directory written by the first flags pass
+    bool narrow_sort = true;          // SA_HIP_NARROW: 8-byte records for initial keys of <= 40 bits (radix_narrow.hpp)
     DevBuf partial, dbg, done;
     bool tiny_finisher = true;        // SA_HIP_TINY: direct-comparison finisher for groups of <= 8
     bool debug_rounds = false;
@@ -880,10 +882,12 @@ struct Builder {
         if (const char* e = getenv("SA_HIP_CHUNK_ROUNDS")) chunk_rounds_before_doubling = atoi(e);
         if (const char* e = getenv("SA_HIP_FUSE_HIST")) fuse_hist = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_FUSE_DIR")) fuse_directory = atoi(e) != 0;
+        if (const char* e = getenv("SA_HIP_NARROW")) narrow_sort = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_TINY")) tiny_finisher = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_DEBUG_ROUNDS")) debug_rounds = atoi(e) != 0;
         if (debug_rounds) { radix.debug_hook = &Builder::sort_debug_hook; radix.debug_ctx = this; }
         if ((rc = radix.init(cap, sort_block))) return rc;
+        if ((rc = narrow.init())) return rc;
         SA_HIP_CHECK(hipEventCreate(&ev_begin));
         SA_HIP_CHECK(hipEventCreate(&ev_end));
         memset(&stats, 0, sizeof stats);
@@ -906,6 +910,7 @@ struct Builder {
                          &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir, &dbg, &done, &pilot};
         for (DevBuf* b : all) b->release();
         radix.destroy();
+        narrow.destroy();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
         if (ev_end) (void)hipEventDestroy(ev_end);
         ev_begin = ev_end = nullptr;
@@ -1156,14 +1161,20 @@ struct Builder {
 
         // initial keys (+ fused digit histograms) + sort #0
         SortPlan pl;
-        if ((rc = make_plan(radix, n32, 64 - b * k0, 64, pl))) return rc;
+        const int begin_bit = 64 - b * k0;
+        if ((rc = make_plan(radix, n32, begin_bit, 64, pl))) return rc;
+        const bool narrow_path = narrow_sort && fuse_hist && narrow_sort_applies(radix, n, begin_bit);
         if (fuse_hist) { if ((rc = radix_prepare(radix, stream))) return rc; }
+        // the narrow sort starts with the TOP digit, the plain LSD sort with the lowest one
         hipLaunchKernelGGL(keygen_kernel, dim3(stream_grid(n, BLD_TILE)), dim3(BLD_BLOCK), 0, stream, text.as<u8>(), n, map, b,
-                           k0, keys0.as<u64>(), pl.g, pl.shift(0), pl.mask(0),
+                           k0, keys0.as<u64>(), pl.g, narrow_path ? 56 : pl.shift(0), narrow_path ? 255u : pl.mask(0),
                            fuse_hist ? radix.hist(0) : (u32*)nullptr);
         u64* kres; u32* vres;
-        if ((rc = radix_sort_pairs(radix, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(), n32,
-                                   64 - b * k0, 64, true, fuse_hist, &kres, &vres))) return rc;
+        if (narrow_path) {
+            if ((rc = radix_sort_narrow(radix, narrow, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(),
+                                        n32, begin_bit, &kres, &vres))) return rc;
+        } else if ((rc = radix_sort_pairs(radix, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(), n32,
+                                          begin_bit, 64, true, fuse_hist, &kres, &vres))) return rc;
         sa = vres;
         qkeys = kres;   // sorted packed keys: kept for the query path (sa_query.hpp)
         qmap = map; q_b = b; q_k0 = k0;
@@ -1309,7 +1320,12 @@ struct Builder {
         stats.radix_ms = radix.timer.total_ms;
         stats.radix_passes = (u32)radix.passes;
         stats.radix_records = radix.pass_records;
-        stats.radix_bytes = radix.pass_records * 2ull * 12ull;
+        stats.radix_bytes = radix.pass_bytes;
+        for (int k = 0; k < PASS_KINDS; ++k) {
+            stats.pass_ms[k] = radix.timer.kind_ms[k];
+            stats.pass_bytes[k] = radix.timer.kind_bytes[k];
+            stats.pass_launches[k] = (u32)radix.timer.kind_launches[k];
+        }
         return 0;
     }
 };

@@ -116,3 +116,37 @@ def test_rebuild_same_handle_is_idempotent(gpu):
         a = idx.build(t).sa_u32().copy()
         b = idx.build(t).sa_u32().copy()
         assert np.array_equal(a, b)
+
+
+def test_narrow_record_sort_matches_plain_sort(gpu, oracle, monkeypatch):
+    """Initial keys of <= 40 bits are sorted in 8-byte records (top digit first, then LSD passes inside
+    the 256 buckets, radix_narrow.hpp); the result must be the plain 12-byte-record sort's, bit for bit:
+    uniform text, a skewed alphabet (one huge bucket, most buckets empty), two symbols, word text; forced
+    key lengths exercise last passes of 1..8 bits; truncated mode keeps ties in text order."""
+    from suffixarray_amd import synth
+    rng = np.random.default_rng(11)
+    skew = rng.choice(np.array([97, 98, 99, 100, 122], dtype=np.uint8), 6_000_000, p=[0.9, 0.04, 0.03, 0.02, 0.01])
+    two = rng.choice(np.array([97, 122], dtype=np.uint8), 5_000_000)
+    runs = [(synth.d1_uniform27(4_500_001), 0, 0), (synth.d1_uniform27(6_000_000), 7, 0), (synth.d1_uniform27(5_000_000), 0, 32),
+            (skew, 13, 0), (skew, 9, 0), (two, 20, 0), (two, 9, 6), (synth.d2_words(8_000_000), 8, 0)]
+    for t, k0, L in runs:
+        if k0:
+            monkeypatch.setenv("SA_HIP_INITIAL_CHARS", str(k0))
+        else:
+            monkeypatch.delenv("SA_HIP_INITIAL_CHARS", raising=False)
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SA_HIP_NARROW", mode)
+            with gpu.DeviceIndex(t.size, 0) as idx:
+                idx.build(t, L)
+                st = idx.build_stats()
+                assert (st["pass_launches"][2] + st["pass_launches"][3] > 0) == (mode == "1"), st
+                assert idx.verify() == 0, st
+                got[mode] = idx.sa_u32().copy()
+        assert np.array_equal(got["1"], got["0"]), (t.size, k0, L)
+    t = runs[0][0]
+    monkeypatch.delenv("SA_HIP_INITIAL_CHARS", raising=False)
+    monkeypatch.setenv("SA_HIP_NARROW", "1")
+    with gpu.DeviceIndex(t.size, 0) as idx:
+        idx.build(t)
+        assert np.array_equal(idx.sa_u32(), oracle.sais(t).astype(np.uint32))

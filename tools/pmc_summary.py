@@ -1,7 +1,7 @@
 """Summarise two rocprofv3 --pmc runs of bench.py (FETCH_SIZE and WRITE_SIZE, separate passes) into
 profiles/pmc_onesweep.json + the per-dispatch CSVs kept beside it.
 
-    python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <tag>
+    python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <tag> [kernel name substring]
 
 Corrections (profiles/r01_c_pmc_calibration.md): counters are in KiB; on gfx950 FETCH_SIZE counts 64 B
 per 128-B request, i.e. half of the bytes (re-calibrated with 8- and 4-byte-per-lane copy kernels);
@@ -9,7 +9,7 @@ WRITE_SIZE is exact."""
 import csv, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "radix_onesweep_kernel"
+KERNEL = sys.argv[4] if len(sys.argv) > 4 else "seg_onesweep_kernel<512, false>"   # substring of the rocprofv3 kernel name
 
 
 def rows(path, counter):
@@ -35,13 +35,13 @@ def main():
             for d, k, g, v in data:
                 o.write("%d,%s,%d,%s,%f\n" % (d, k.split("(")[0].replace("void sa::", ""), g, cname, v))
     j = {
-        "kernel": "radix_onesweep_kernel<512>",
-        "workload": "bench.py default: D1 uniform27 N=1e9, k0=8: 5 passes over N per build",
+        "kernel": KERNEL,
+        "workload": "bench.py default: D1 uniform27 N=1e9, k0=8 (40-bit keys): top-digit pass + 3 passes of this kernel + last pass per build",
         "launches": n,
         "fetch_bytes_total": sum(fb),
         "write_bytes_total": sum(wb),
         "traffic_bytes_per_launch": (sum(fb) + sum(wb)) / n,
-        "algorithmic_bytes_per_launch": 24000000000.0,
+        "algorithmic_bytes_per_launch": 16000000000.0 if "seg_onesweep_kernel<512, false>" in KERNEL else None,
         "corrections": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request; calibrated with 8-byte and 4-byte-per-lane copy "
                        "kernels in tools/sortbench.hip), WRITE_SIZE exact, counters in KiB",
         "commands": [

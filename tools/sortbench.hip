@@ -81,7 +81,7 @@ float run_pass(RadixWorkspace& ws, hipStream_t st, u64* k0, u32* v0, u64* k1, u3
         SortPassArgs a;
         a.keys_in = k0; a.vals_in = v0; a.keys_out = k1; a.vals_out = v1; a.g = g; a.shift = shift; a.mask = 255u;
         a.next_shift = shift + 8; a.next_mask = 255u; a.next_hist = ws.hist(1);
-        a.digit_base = ws.base(); a.status = ws.status; a.ticket = ws.tickets(); a.epoch = ++ws.epoch; a.dstat = ws.dstat; a.home_mode = home_mode; a.incl_mask = incl_mask;
+        a.digit_base = ws.base(); a.status = ws.status; a.ticket = ws.tickets(); a.epoch = ++ws.epoch; a.dstat = ws.dstat; a.home_mode = home_mode; a.incl_mask = incl_mask; a.keys_out32 = nullptr; a.narrow_shift = 0;
         CK(hipEventRecord(e0, st));
         hipLaunchKernelGGL((radix_onesweep_kernel<BLOCK, ABL>), dim3(g.tiles), dim3(BLOCK), 0, st, a);
         CK(hipEventRecord(e1, st));
