@@ -10,7 +10,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libsa_hip.so")
 SOURCES = ["sa_capi.hip"]
-HEADERS = ["common.hpp", "radix_sort.hpp", "sa_build.hpp", "sa_query.hpp", os.path.join("..", "..", "include", "sa_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
@@ -19,7 +18,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "sa_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 

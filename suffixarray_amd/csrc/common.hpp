@@ -64,6 +64,11 @@ __device__ __forceinline__ void sync_lds() {
     __syncthreads();
 }
 
+// Alphabet compaction of a text: code = 1 + rank of the byte among the bytes that occur; 0 = past the end.
+struct CodeMap {
+    u16 code[256];  // 0 = byte absent (never looked up for a present position); 1..sigma
+};
+
 // Device error word shared by every kernel that can spin (decoupled look-back).
 // 0 = ok; anything else = a bounded spin expired, results are invalid.
 struct DeviceStatus {

@@ -86,30 +86,44 @@ __device__ __forceinline__ u32 seg_bucket_of(const u32* tprefix, u32 f) {
     return lo;
 }
 
-// histogram of digit [shift, shift + 8) of the narrow keys, per bucket: hist[b][d]
+// histogram of digit [shift, shift + 8) of the narrow keys, per bucket: hist[b][d]; the LDS histogram is kept in
+// SEG_HIST_COPIES lane-selected copies (fewer lanes of a wave on the same counter)
+constexpr int SEG_HIST_COPIES = 4;
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void seg_hist_kernel(const u32* __restrict__ keys, const SegPlan* __restrict__ plan, int shift,
                                                          u32 mask, u32* __restrict__ hist, u32 tiles_per_block) {
     constexpr u32 TILE = BLOCK * SORT_ITEMS;
-    __shared__ u32 s_h[RADIX];
+    constexpr int CS = RADIX + 1;
+    __shared__ u32 s_h[SEG_HIST_COPIES * CS];
     __shared__ u32 s_t[RADIX + 1];
     for (int i = threadIdx.x; i <= RADIX; i += BLOCK) s_t[i] = plan->tprefix[i];
-    for (int i = threadIdx.x; i < RADIX; i += BLOCK) s_h[i] = 0;
+    for (int i = threadIdx.x; i < SEG_HIST_COPIES * CS; i += BLOCK) s_h[i] = 0;
     __syncthreads();
     const u32 F = s_t[RADIX];
     const u32 f_lo = blockIdx.x * tiles_per_block;
     const u32 f_hi = (f_lo + tiles_per_block < F) ? f_lo + tiles_per_block : F;
     if (f_lo >= f_hi) return;
+    u32* my = s_h + (threadIdx.x & (SEG_HIST_COPIES - 1)) * CS;
+    auto flush = [&](u32 bucket) {
+        sync_lds();
+        for (int d = threadIdx.x; d < RADIX; d += BLOCK) {
+            u32 v = 0;
+#pragma unroll
+            for (int k = 0; k < SEG_HIST_COPIES; ++k) { v += s_h[k * CS + d]; s_h[k * CS + d] = 0; }
+            if (v) atomicAdd(&hist[bucket * RADIX + d], v);
+        }
+        sync_lds();
+    };
     u32 cur = seg_bucket_of(s_t, f_lo);
     for (u32 f = f_lo; f < f_hi; ++f) {
         const u32 b = seg_bucket_of(s_t, f);
-        if (b != cur) { hist_flush(s_h, hist, cur); cur = b; }
+        if (b != cur) { flush(cur); cur = b; }
         const u32 start = plan->bstart[b] + ((f - s_t[b]) * TILE);
         const u32 end = plan->bstart[b + 1];
         const u32 len = (end - start) < TILE ? (end - start) : TILE;
-        for (u32 l = threadIdx.x; l < len; l += BLOCK) atomicAdd(&s_h[(keys[start + l] >> shift) & mask], 1u);
+        for (u32 l = threadIdx.x; l < len; l += BLOCK) atomicAdd(&my[(keys[start + l] >> shift) & mask], 1u);
     }
-    hist_flush(s_h, hist, cur);
+    flush(cur);
 }
 
 // base[b][d] = bstart[b] + sum_{d' < d} hist[b][d']; one workgroup of 256 per bucket
@@ -152,30 +166,30 @@ struct SegPassArgs {
     u32 incl_mask;
 };
 
-template <bool FULL, int BLOCK, bool LAST>
+template <bool FULL, int BLOCK, int ITEMS, bool LAST>
 __device__ __forceinline__ void seg_tile(const SegPassArgs& a, const u32 flat, const u32 first_flat, const u32 bucket,
                                          const u32 start, const u32 tile_n, u32* s_keys, u32* s_whist, u32* s_gdelta,
                                          u32* s_wsum) {
     constexpr int WAVES = BLOCK / WAVE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u32 woff = (u32)wave * (WAVE * SORT_ITEMS) + lane;
+    const u32 woff = (u32)wave * (WAVE * ITEMS) + lane;
 
     // 1. load (wave-striped)
-    u32 key[SORT_ITEMS];
+    u32 key[ITEMS];
     const u32* kin = a.keys_in + start;
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
+    for (int j = 0; j < ITEMS; ++j) {
         const u32 p = woff + j * WAVE;
         key[j] = (FULL || p < tile_n) ? kin[p] : ~0u;
     }
     // 2. rank
-    u32 rd[SORT_ITEMS];
+    u32 rd[ITEMS];
     u32* wh = s_whist + wave * RADIX;
     wave_rank<FULL>(key, a.shift, a.mask, woff, tile_n, wh, rd);
-    u32 val[SORT_ITEMS];
+    u32 val[ITEMS];
     const u32* vin = a.vals_in + start;
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
+    for (int j = 0; j < ITEMS; ++j) {
         const u32 p = woff + j * WAVE;
         val[j] = (FULL || p < tile_n) ? vin[p] : 0u;
     }
@@ -213,9 +227,9 @@ __device__ __forceinline__ void seg_tile(const SegPassArgs& a, const u32 flat, c
     __syncthreads();
 
     // 4. keys -> LDS at their tile-local sorted position
-    u32 pos[SORT_ITEMS];
+    u32 pos[ITEMS];
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
+    for (int j = 0; j < ITEMS; ++j) {
         pos[j] = wh[rd[j] >> 16] + (rd[j] & 0xFFFFu);
         if (FULL || (woff + j * WAVE) < tile_n) s_keys[pos[j]] = key[j];
     }
@@ -237,9 +251,9 @@ __device__ __forceinline__ void seg_tile(const SegPassArgs& a, const u32 flat, c
     __syncthreads();
 
     // 6. coalesced stores per digit run
-    u32 gidx[SORT_ITEMS];
+    u32 gidx[ITEMS];
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
         const u32 p = k * BLOCK + tid;
         if (FULL || p < tile_n) {
             const u32 kk = s_keys[p];
@@ -260,20 +274,23 @@ __device__ __forceinline__ void seg_tile(const SegPassArgs& a, const u32 flat, c
     }
     u32* s_vals = s_keys;
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j)
+    for (int j = 0; j < ITEMS; ++j)
         if (FULL || (woff + j * WAVE) < tile_n) s_vals[pos[j]] = val[j];
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
         const u32 p = k * BLOCK + tid;
         if (FULL || p < tile_n) a.vals_out[gidx[k]] = s_vals[p];
     }
 }
 
-template <int BLOCK, bool LAST>
-__global__ __launch_bounds__(BLOCK, 4) void seg_onesweep_kernel(SegPassArgs a) {
+// BLOCK x ITEMS = 512 x 16 (4 waves per SIMD at <= 128 VGPRs) or 1024 x 8 (8 waves per SIMD at <= 64): the same
+// 8192-record tile and the same LDS either way, twice the waves to hide the ranking and look-back chains
+template <int BLOCK, int ITEMS, bool LAST>
+__global__ __launch_bounds__(BLOCK, (BLOCK == 1024) ? 8 : 4) void seg_onesweep_kernel(SegPassArgs a) {
     constexpr int WAVES = BLOCK / WAVE;
-    constexpr u32 TILE = BLOCK * SORT_ITEMS;
+    constexpr u32 TILE = BLOCK * ITEMS;
+    static_assert(TILE == 512 * SORT_ITEMS, "the plan's tile size");
     __shared__ __attribute__((aligned(16))) u32 s_keys[TILE];   // reused for the values
     __shared__ u32 s_whist[WAVES * RADIX];
     __shared__ u32 s_gdelta[RADIX];
@@ -313,9 +330,280 @@ __global__ __launch_bounds__(BLOCK, 4) void seg_onesweep_kernel(SegPassArgs a) {
     const u32 start = a.plan->bstart[bucket] + (flat - first_flat) * TILE;
     const u32 rest = a.plan->bstart[bucket + 1] - start;
     if (rest >= TILE)
-        seg_tile<true, BLOCK, LAST>(a, flat, first_flat, bucket, start, TILE, s_keys, s_whist, s_gdelta, s_wsum);
+        seg_tile<true, BLOCK, ITEMS, LAST>(a, flat, first_flat, bucket, start, TILE, s_keys, s_whist, s_gdelta, s_wsum);
     else
-        seg_tile<false, BLOCK, LAST>(a, flat, first_flat, bucket, start, rest, s_keys, s_whist, s_gdelta, s_wsum);
+        seg_tile<false, BLOCK, ITEMS, LAST>(a, flat, first_flat, bucket, start, rest, s_keys, s_whist, s_gdelta, s_wsum);
+}
+
+// ---- histogram of the top digit, per chunk of the input order, straight from the text -----------------------
+// hist[chunk][d], d = top 8 bits of the key of every position = its first c8 = ceil(8 / b) characters.  Every
+// thread owns 16 consecutive positions (one 16-byte load + the next one for the c8 - 1 characters that
+// follow), rolls a c8-character window over them and counts into one of TOP_HIST_COPIES LDS histograms.
+constexpr int TOP_HIST_COPIES = 8;
+__global__ __launch_bounds__(256) void top_hist_kernel(const u8* __restrict__ text, const u16* __restrict__ map, u64 n, int b,
+                                                       SortGeom g, u32* __restrict__ hist) {
+    constexpr int CS = RADIX + 1;
+    constexpr u32 SPAN = 256 * 16;
+    __shared__ u32 s_h[TOP_HIST_COPIES * CS];
+    __shared__ u8 s_map[256];
+    s_map[threadIdx.x] = (u8)map[threadIdx.x];
+    for (int i = threadIdx.x; i < TOP_HIST_COPIES * CS; i += 256) s_h[i] = 0;
+    __syncthreads();
+    u32* my = s_h + (threadIdx.x & (TOP_HIST_COPIES - 1)) * CS;
+    const int c8 = (8 + b - 1) / b;
+    const u32 wmask = (1u << (c8 * b)) - 1u;
+    const int dshift = c8 * b - 8;
+    const u64 nspans = (n + SPAN - 1) / SPAN;
+    const u64 per = (nspans + gridDim.x - 1) / gridDim.x;
+    const u64 s_lo = (u64)blockIdx.x * per;
+    const u64 s_hi = (s_lo + per < nspans) ? s_lo + per : nspans;
+    auto flush = [&](u32 chunk) {
+        sync_lds();
+        u32 v = 0;
+#pragma unroll
+        for (int k = 0; k < TOP_HIST_COPIES; ++k) { v += s_h[k * CS + threadIdx.x]; s_h[k * CS + threadIdx.x] = 0; }
+        if (v) atomicAdd(&hist[chunk * RADIX + threadIdx.x], v);
+        sync_lds();
+    };
+    if (s_lo >= s_hi) return;
+    u32 cur = chunk_of_tile((u32)((s_lo * SPAN) >> g.tile_shift), g.tpc);
+    for (u64 sp = s_lo; sp < s_hi; ++sp) {
+        const u64 base = sp * SPAN;
+        const u32 c = chunk_of_tile((u32)(base >> g.tile_shift), g.tpc);   // a chunk is a whole number of 8192-record tiles = spans
+        if (c != cur) { flush(cur); cur = c; }
+        const u64 p0 = base + (u64)threadIdx.x * 16;
+        if (p0 < n) {
+            // 32 bytes from p0 (the buffer is readable TEXT_PAD >= 32 bytes past n)
+            const uint4 x0 = *reinterpret_cast<const uint4*>(text + p0);
+            const uint4 x1 = *reinterpret_cast<const uint4*>(text + p0 + 16);
+            const u32 w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            const u32 live = (n - p0 < 32) ? (u32)(n - p0) : 32u;   // bytes of the text among the 32
+            u32 win = 0;
+#pragma unroll
+            for (int k = 0; k < 16 + 7; ++k) {
+                if (k >= 16 + c8 - 1) break;
+                const u32 byte = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
+                const u32 code = ((u32)k < live) ? (u32)s_map[byte] : 0u;
+                win = ((win << b) | code) & wmask;
+                const int i = k - (c8 - 1);   // the window now ends at k: it is the one of position p0 + i
+                if (i >= 0 && (u32)i < live) atomicAdd(&my[win >> dshift], 1u);
+            }
+        }
+    }
+    flush(cur);
+}
+
+// ---- top-digit pass straight from the text -------------------------------------------------------------
+// The u64 keys of the top-digit pass exist only to be read once: this kernel assembles them in registers
+// from the text instead (no key array, no key-generation kernel: 1 byte read + 8 bytes written per record
+// instead of 9 + 16).  A tile's text bytes (+ a halo of k0 - 1) are staged in LDS as alphabet codes;
+// every lane builds the keys of its 16 wave-striped positions character by character (one LDS byte read
+// and one shift-or per character and key), ranks them by the top digit and the pass proceeds as in
+// radix_onesweep_kernel with iota values; the top digit of a sorted slot travels through LDS beside the
+// narrow key (the narrow key does not contain it).
+struct TextPassArgs {
+    const u8* text;
+    const u16* map;         // CodeMap::code in device memory
+    u64 n;
+    int b, k0, begin_bit;   // key = k0 characters of b bits, MSB first, in bits [begin_bit, 64); b <= 8
+    u32* keys_out32;        // (u32)(key >> begin_bit)
+    u32* vals_out;          // text position
+    SortGeom g;
+    const u32* digit_base;  // [NCHUNK][RADIX] of the top digit
+    u64* status;
+    u32* ticket;
+    u32 epoch;
+    DeviceStatus* dstat;
+    u32 incl_mask;
+};
+constexpr int TEXT_HALO = 64;   // >= k0 - 1 (k0 * b <= 40)
+
+template <bool FULL, int BLOCK>
+__device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 tile, const u32 chunk,
+                                              const u32 tile_n, u32* s_keys, u32* s_whist, u32* s_gdelta, u32* s_wsum,
+                                              u8* s_code, const u8* s_map) {
+    constexpr int WAVES = BLOCK / WAVE;
+    constexpr int ITEMS = SORT_ITEMS;
+    constexpr u32 TILE = BLOCK * ITEMS;
+    static_assert(TILE == BLOCK * 16, "one 16-byte text load per thread");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 first_tile = chunk * a.g.tpc;
+    const u64 tile_base = (u64)tile * TILE;
+    const u32 woff = (u32)wave * (WAVE * ITEMS) + lane;
+
+    // 0. text -> codes in LDS: 16 bytes per thread, the halo by the first TEXT_HALO / 16 threads
+    //    (the text buffer is readable for TEXT_PAD >= 16 bytes past n; a load starts below n or is skipped)
+    auto stage16 = [&](u32 local, auto checked) {
+        constexpr bool CHECK = decltype(checked)::value;   // false: all 16 positions are known to lie below n
+        const u64 p0 = tile_base + local;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (!CHECK || p0 < a.n) x = *reinterpret_cast<const uint4*>(a.text + p0);
+        const u32 w[4] = {x.x, x.y, x.z, x.w};
+        const u32 live = CHECK ? (u32)((a.n > p0) ? ((a.n - p0 < 16) ? (a.n - p0) : 16) : 0) : 16u;
+        u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const u32 byte = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
+            const u32 code = (!CHECK || (u32)k < live) ? (u32)s_map[byte] : 0u;
+            o[k >> 2] |= code << ((k & 3) * 8);
+        }
+        *reinterpret_cast<uint4*>(s_code + local) = make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    if (FULL) stage16((u32)tid * 16u, std::false_type{}); else stage16((u32)tid * 16u, std::true_type{});
+    if (tid < TEXT_HALO / 16) stage16(TILE + (u32)tid * 16u, std::true_type{});
+    __syncthreads();
+
+    // 1. keys of the lane's positions woff + 64 j, one character per step: hi:lo = bits [32,64):[0,32)
+    u32 hi[ITEMS], lo[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) { hi[j] = 0; lo[j] = 0; }
+    const u8* cp = s_code + woff;
+    int sh = 64;
+    for (int c = 0; c < a.k0; ++c, ++cp) {
+        sh -= a.b;
+        if (sh >= 32) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) hi[j] |= (u32)cp[j * WAVE] << (sh - 32);
+        } else if (sh + a.b <= 32) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) lo[j] |= (u32)cp[j * WAVE] << sh;
+        } else {   // the character straddles bit 32
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const u32 code = cp[j * WAVE];
+                hi[j] |= code >> (32 - sh);
+                lo[j] |= code << sh;
+            }
+        }
+    }
+    u32 key[ITEMS];   // narrow keys: bits [begin_bit, begin_bit + 32) of hi:lo
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+        key[j] = (a.begin_bit >= 32) ? (hi[j] >> (a.begin_bit - 32)) : __builtin_amdgcn_alignbit(hi[j], lo[j], (u32)a.begin_bit);
+
+    // 2. rank by the top digit (bits 24..31 of hi)
+    u32 rd[ITEMS];
+    u32* wh = s_whist + wave * RADIX;
+    wave_rank<FULL>(hi, 24, 255u, woff, tile_n, wh, rd);
+    __syncthreads();   // also: every read of s_code is done (it becomes the digit array below)
+
+    // 3. tile digit counts -> aggregate -> exclusive scan over digits
+    u32 count = 0, excl = 0;
+    if (tid < RADIX) {
+        u32 c = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const u32 t = s_whist[w * RADIX + tid];
+            s_whist[w * RADIX + tid] = c;
+            c += t;
+        }
+        count = c;
+        __hip_atomic_store(&a.status[(u64)tile * RADIX + tid],
+                           pack_status(a.epoch, tile == first_tile ? FLAG_INCL : FLAG_AGG, count),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u32 incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        excl = incl - c;
+    }
+    __syncthreads();
+    if (tid < RADIX) {
+        for (int i = 0; i < wave; ++i) excl += s_wsum[i];
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) s_whist[w * RADIX + tid] += excl;
+    }
+    __syncthreads();
+
+    // 4. narrow keys and their top digits -> LDS at the tile-local sorted position
+    u8* s_dig = s_code;
+    u32 pos[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 d = rd[j] >> 16;
+        pos[j] = wh[d] + (rd[j] & 0xFFFFu);
+        if (FULL || (woff + j * WAVE) < tile_n) { s_keys[pos[j]] = key[j]; s_dig[pos[j]] = (u8)d; }
+    }
+    __syncthreads();
+
+    // 5. look-back
+    if (tid < RADIX) {
+        u32 prefix = 0;
+        if (tile > first_tile) {
+            prefix = lookback_prefix(a.status, tile, first_tile, (u32)tid, a.epoch, a.dstat);
+            if (((tile - first_tile) & a.incl_mask) == a.incl_mask)
+                __hip_atomic_store(&a.status[(u64)tile * RADIX + tid], pack_status(a.epoch, FLAG_INCL, prefix + count),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_gdelta[tid] = a.digit_base[chunk * RADIX + tid] + prefix - excl;
+    }
+    __syncthreads();
+
+    // 6. coalesced stores per digit run: keys, then the positions
+    u32 gidx[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const u32 p = k * BLOCK + tid;
+        if (FULL || p < tile_n) {
+            gidx[k] = s_gdelta[s_dig[p]] + p;
+            a.keys_out32[gidx[k]] = s_keys[p];
+        }
+    }
+    __syncthreads();
+    u32* s_vals = s_keys;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+        if (FULL || (woff + j * WAVE) < tile_n) s_vals[pos[j]] = (u32)tile_base + woff + j * WAVE;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const u32 p = k * BLOCK + tid;
+        if (FULL || p < tile_n) a.vals_out[gidx[k]] = s_vals[p];
+    }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 4) void text_top_pass_kernel(TextPassArgs a) {
+    constexpr int WAVES = BLOCK / WAVE;
+    constexpr u32 TILE = BLOCK * SORT_ITEMS;
+    __shared__ __attribute__((aligned(16))) u32 s_keys[TILE];
+    __shared__ u32 s_whist[WAVES * RADIX];
+    __shared__ u32 s_gdelta[RADIX];
+    __shared__ u32 s_wsum[RADIX / WAVE];
+    __shared__ __attribute__((aligned(16))) u8 s_code[TILE + TEXT_HALO];   // codes, later the top digit per sorted slot
+    __shared__ u8 s_map[256];
+    __shared__ u32 s_tile;
+    __shared__ u32 s_chunk;
+
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        u32 tile = 0xFFFFFFFFu, chunk = 0;
+        const u32 home = xcc_id();
+        for (int k = 0; k < NCHUNK; ++k) {
+            const u32 c = (home + k) & (NCHUNK - 1);
+            const u32 first = c * a.g.tpc;
+            if (first >= a.g.tiles) continue;
+            const u32 cnt = (a.g.tiles - first) < a.g.tpc ? (a.g.tiles - first) : a.g.tpc;
+            const u32 t = atomicAdd(&a.ticket[c], 1u);
+            if (t < cnt) { tile = first + t; chunk = c; break; }
+        }
+        s_tile = tile;
+        s_chunk = chunk;
+    }
+    if (tid < 256) s_map[tid] = (u8)a.map[tid];
+    for (int i = tid; i < WAVES * RADIX; i += BLOCK) s_whist[i] = 0;
+    __syncthreads();
+    const u32 tile = s_tile;
+    if (tile == 0xFFFFFFFFu) return;
+    const u32 chunk = s_chunk;
+    const u64 rest = a.n - (u64)tile * TILE;
+    if (rest >= (u64)TILE)
+        text_top_tile<true, BLOCK>(a, tile, chunk, TILE, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
+    else
+        text_top_tile<false, BLOCK>(a, tile, chunk, (u32)rest, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
 }
 
 // ---- host driver --------------------------------------------------------------------------------------
@@ -324,12 +612,17 @@ struct NarrowWorkspace {
     u32* hist = nullptr;     // [NARROW_MAX_PASSES][RADIX][RADIX]
     u32* base = nullptr;     // [RADIX][RADIX]
     u32* tickets = nullptr;  // [NARROW_MAX_PASSES][NCHUNK]
+    bool wide_block = false; // SA_HIP_NARROW_BLOCK=1024: 1024 x 8 workgroups instead of 512 x 16
+    u16* map_dev = nullptr;  // CodeMap of the text pass
+    CodeMap map_host;        // source of the asynchronous copy (must outlive the call)
     static size_t hist_bytes() { return (size_t)NARROW_MAX_PASSES * RADIX * RADIX * sizeof(u32); }
     int init() {
+        if (const char* e = getenv("SA_HIP_NARROW_BLOCK")) wide_block = atoi(e) == 1024;
         SA_HIP_CHECK(hipMalloc(&plan, sizeof(SegPlan)));
         SA_HIP_CHECK(hipMalloc(&hist, hist_bytes()));
         SA_HIP_CHECK(hipMalloc(&base, (size_t)RADIX * RADIX * sizeof(u32)));
         SA_HIP_CHECK(hipMalloc(&tickets, (size_t)NARROW_MAX_PASSES * NCHUNK * sizeof(u32)));
+        SA_HIP_CHECK(hipMalloc(&map_dev, sizeof(CodeMap)));
         return 0;
     }
     void destroy() {
@@ -337,6 +630,8 @@ struct NarrowWorkspace {
         if (hist) (void)hipFree(hist);
         if (base) (void)hipFree(base);
         if (tickets) (void)hipFree(tickets);
+        if (map_dev) (void)hipFree(map_dev);
+        map_dev = nullptr;
         plan = nullptr; hist = nullptr; base = nullptr; tickets = nullptr;
     }
 };
@@ -348,12 +643,32 @@ inline bool narrow_sort_applies(const RadixWorkspace& ws, u64 n, int begin_bit) 
            n / ws.tile() + RADIX + 1 <= ws.max_tiles;
 }
 
-// Sort n records (keysA[i], i) by key bits [begin_bit, 64), stable.  keysA holds the u64 keys and the
+// Where the keys come from when the top-digit pass reads the text itself (text_top_pass_kernel)
+struct TextSource {
+    const u8* text;
+    int b, k0;
+};
+inline bool text_pass_applies(int b, int k0) { return b <= 8 && k0 - 1 <= TEXT_HALO; }
+
+// Code map to the device + per-chunk histogram of the top digit of every position's key into ws.hist(0)
+// (radix_prepare() before): what a text-sourced narrow sort needs in place of key generation.
+inline int narrow_text_histogram(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_t stream, const u8* text, const CodeMap& map,
+                                 u32 n, int b) {
+    nw.map_host = map;
+    SA_HIP_CHECK(hipMemcpyAsync(nw.map_dev, nw.map_host.code, sizeof(CodeMap), hipMemcpyHostToDevice, stream));
+    const SortGeom g = make_geom(n, ws.tile());
+    const u32 spans = div_up(n, 4096);
+    hipLaunchKernelGGL(top_hist_kernel, dim3(spans < 2048u ? spans : 2048u), dim3(256), 0, stream, text, nw.map_dev, (u64)n, b, g, ws.hist(0));
+    return 0;
+}
+
+// Sort n records (keysA[i], i) by key bits [begin_bit, 64), stable.  src != nullptr: keysA holds nothing yet,
+// the keys are the first src->k0 characters of every text position (ws.hist(0) must be ready: narrow_text_histogram).  keysA holds the u64 keys and the
 // histogram of their top digit has been accumulated into ws.hist(0) by the producer (radix_prepare() before).
 // keysA / keysB and valsA / valsB are the ping-pong buffers of the plain sort (n * 8 and n * 4 bytes);
 // narrow keys use the first n * 4 bytes of a key buffer.  Result: *keys_res (u64, full keys), *vals_res.
 inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_t stream, u64* keysA, u32* valsA, u64* keysB,
-                             u32* valsB, u32 n, int begin_bit, u64** keys_res, u32** vals_res) {
+                             u32* valsB, u32 n, int begin_bit, u64** keys_res, u32** vals_res, const TextSource* src = nullptr) {
     int rc;
     const int lo_bits = 56 - begin_bit;                       // 1 .. 32
     const int np = (lo_bits + RADIX_BITS - 1) / RADIX_BITS;   // narrow passes, 1 .. 4
@@ -368,6 +683,16 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
             ws.epoch = 1;
         }
         hipLaunchKernelGGL(radix_scan_hist_kernel, dim3(1), dim3(256), 0, stream, ws.hist(0), ws.base());
+        if (src) {
+            TextPassArgs t;
+            t.text = src->text; t.map = nw.map_dev; t.n = n; t.b = src->b; t.k0 = src->k0; t.begin_bit = begin_bit;
+            t.keys_out32 = reinterpret_cast<u32*>(keysB); t.vals_out = valsB; t.g = g; t.digit_base = ws.base();
+            t.status = ws.status; t.ticket = ws.tickets(); t.epoch = ws.epoch; t.dstat = ws.dstat; t.incl_mask = SA_INCL_MASK;
+            if ((rc = ws.timer.start(stream, 1))) return rc;
+            hipLaunchKernelGGL((text_top_pass_kernel<512>), dim3(g.tiles), dim3(512), 0, stream, t);
+            if ((rc = ws.timer.stop(stream, (u64)n * 9u))) return rc;
+            ws.pass_records += n; ws.pass_bytes += (u64)n * 9u; ws.passes += 1;
+        } else {
         SortPassArgs a;
         a.keys_in = keysA; a.vals_in = nullptr; a.keys_out = nullptr; a.vals_out = valsB;
         a.g = g; a.shift = 56; a.mask = 255u; a.next_shift = -1; a.next_mask = 0; a.digit_base = ws.base();
@@ -378,6 +703,7 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
         hipLaunchKernelGGL((radix_onesweep_kernel<512, 0, true>), dim3(g.tiles), dim3(512), 0, stream, a);
         if ((rc = ws.timer.stop(stream, (u64)n * 16u))) return rc;
         ws.pass_records += n; ws.pass_bytes += (u64)n * 16u; ws.passes += 1;
+        }
     }
     hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(256), 0, stream, ws.hist(0), g.tile_shift, nw.plan);
     const u32 flat_max = g.tiles + RADIX;   // >= sum over buckets of ceil(size / tile)
@@ -411,8 +737,13 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
         a.status = ws.status; a.ticket = nw.tickets + p * NCHUNK; a.epoch = ws.epoch; a.dstat = ws.dstat;
         a.lo_shift = begin_bit; a.incl_mask = SA_INCL_MASK;
         if ((rc = ws.timer.start(stream, last ? 3 : 2))) return rc;
-        if (last) hipLaunchKernelGGL((seg_onesweep_kernel<512, true>), dim3(flat_max), dim3(512), 0, stream, a);
-        else hipLaunchKernelGGL((seg_onesweep_kernel<512, false>), dim3(flat_max), dim3(512), 0, stream, a);
+        if (nw.wide_block) {
+            if (last) hipLaunchKernelGGL((seg_onesweep_kernel<1024, 8, true>), dim3(flat_max), dim3(1024), 0, stream, a);
+            else hipLaunchKernelGGL((seg_onesweep_kernel<1024, 8, false>), dim3(flat_max), dim3(1024), 0, stream, a);
+        } else {
+            if (last) hipLaunchKernelGGL((seg_onesweep_kernel<512, 16, true>), dim3(flat_max), dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((seg_onesweep_kernel<512, 16, false>), dim3(flat_max), dim3(512), 0, stream, a);
+        }
         if ((rc = ws.timer.stop(stream, (u64)n * (last ? 20u : 16u)))) return rc;
         ws.pass_records += n; ws.pass_bytes += (u64)n * (last ? 20u : 16u); ws.passes += 1;
         u32* tk = kin; kin = kout; kout = tk;

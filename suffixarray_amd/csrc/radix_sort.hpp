@@ -234,17 +234,18 @@ __device__ __forceinline__ u32 lookback_prefix(const u64* __restrict__ status, u
 // ABL: ablation mask for tools/sortbench.hip only (0 in the product): 1 = no look-back (every tile
 // of a chunk then writes to the same place: the stores stay in cache, NOT a bandwidth figure),
 // 4 = no values, 8 = stores not scattered (streaming copy), 16 = no next-pass histogram.
-// Per-wave stable ranking of SORT_ITEMS wave-striped records by one digit: rd[j] = (number of records of
+// Per-wave stable ranking of ITEMS wave-striped records per lane by one digit: rd[j] = (number of records of
 // this wave with the same digit that precede record j in memory order) | digit << 16; wh[digit] ends as
 // the wave's digit count.  Two records at a time (two independent instruction streams); per digit bit
 // ONE v_bfe_i32 (e = -bit), ONE v_cmp (the ballot) and one three-input bit operation per 32-bit half of
 // the peer mask.  The empty asm statements keep the compiler from re-associating the mask updates into
 // longer chains of two-input operations.
-template <bool FULL, typename KeyT>
-__device__ __forceinline__ void wave_rank(const KeyT (&key)[SORT_ITEMS], int shift, u32 mask, u32 woff, u32 tile_n,
-                                          u32* wh, u32 (&rd)[SORT_ITEMS]) {
+template <bool FULL, typename KeyT, int ITEMS>
+__device__ __forceinline__ void wave_rank(const KeyT (&key)[ITEMS], int shift, u32 mask, u32 woff, u32 tile_n,
+                                          u32* wh, u32 (&rd)[ITEMS]) {
+    static_assert(ITEMS % 2 == 0, "records are ranked in pairs");
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; j += 2) {
+    for (int j = 0; j < ITEMS; j += 2) {
         bool valid[2];
         u32 d[2], lo[2], hi[2];
 #pragma unroll

@@ -33,9 +33,6 @@ constexpr int BLD_ITEMS = 16;
 constexpr int BLD_TILE = BLD_BLOCK * BLD_ITEMS;  // 4096 elements per workgroup
 constexpr u32 NONE32 = 0xFFFFFFFFu;
 
-struct CodeMap {
-    u16 code[256];  // 0 = byte absent (never looked up for a present position); 1..sigma
-};
 
 // ---- byte histogram (libsais `freq`, libsais.c:1363-1371) -------------------------------------
 // Small alphabets put many lanes of a wave on the same counter (LDS atomics to one address serialise),
@@ -832,6 +829,7 @@ struct Builder {
     DevBuf pilot;
     bool fuse_hist = true;            // SA_HIP_FUSE_HIST: digit histograms inside keygen
     bool fuse_directory = true;       // SA_HIP_FUSE_DIR: query directory written by the first flags pass
+    bool text_top_pass = true;        // SA_HIP_TEXT_PASS: the top-digit pass of a narrow sort builds its keys from the text
     bool narrow_sort = true;          // SA_HIP_NARROW: 8-byte records for initial keys of <= 40 bits (radix_narrow.hpp)
     DevBuf partial, dbg, done;
     bool tiny_finisher = true;        // SA_HIP_TINY: direct-comparison finisher for groups of <= 8
@@ -883,6 +881,7 @@ struct Builder {
         if (const char* e = getenv("SA_HIP_FUSE_HIST")) fuse_hist = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_FUSE_DIR")) fuse_directory = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_NARROW")) narrow_sort = atoi(e) != 0;
+        if (const char* e = getenv("SA_HIP_TEXT_PASS")) text_top_pass = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_TINY")) tiny_finisher = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_DEBUG_ROUNDS")) debug_rounds = atoi(e) != 0;
         if (debug_rounds) { radix.debug_hook = &Builder::sort_debug_hook; radix.debug_ctx = this; }
@@ -1165,14 +1164,22 @@ struct Builder {
         if ((rc = make_plan(radix, n32, begin_bit, 64, pl))) return rc;
         const bool narrow_path = narrow_sort && fuse_hist && narrow_sort_applies(radix, n, begin_bit);
         if (fuse_hist) { if ((rc = radix_prepare(radix, stream))) return rc; }
-        // the narrow sort starts with the TOP digit, the plain LSD sort with the lowest one
-        hipLaunchKernelGGL(keygen_kernel, dim3(stream_grid(n, BLD_TILE)), dim3(BLD_BLOCK), 0, stream, text.as<u8>(), n, map, b,
-                           k0, keys0.as<u64>(), pl.g, narrow_path ? 56 : pl.shift(0), narrow_path ? 255u : pl.mask(0),
-                           fuse_hist ? radix.hist(0) : (u32*)nullptr);
+        // the narrow sort starts with the TOP digit, the plain LSD sort with the lowest one; when the top-digit
+        // pass reads the text itself, key generation shrinks to the histogram of that digit
+        const bool text_pass = narrow_path && text_top_pass && text_pass_applies(b, k0);
+        if (text_pass) {
+            if ((rc = narrow_text_histogram(radix, narrow, stream, text.as<u8>(), map, n32, b))) return rc;
+        } else {
+            hipLaunchKernelGGL(keygen_kernel, dim3(stream_grid(n, BLD_TILE)), dim3(BLD_BLOCK), 0, stream, text.as<u8>(), n, map, b,
+                               k0, keys0.as<u64>(), pl.g, narrow_path ? 56 : pl.shift(0), narrow_path ? 255u : pl.mask(0),
+                               fuse_hist ? radix.hist(0) : (u32*)nullptr);
+        }
         u64* kres; u32* vres;
         if (narrow_path) {
+            TextSource src;
+            src.text = text.as<u8>(); src.b = b; src.k0 = k0;
             if ((rc = radix_sort_narrow(radix, narrow, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(),
-                                        n32, begin_bit, &kres, &vres))) return rc;
+                                        n32, begin_bit, &kres, &vres, text_pass ? &src : nullptr))) return rc;
         } else if ((rc = radix_sort_pairs(radix, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(), n32,
                                           begin_bit, 64, true, fuse_hist, &kres, &vres))) return rc;
         sa = vres;

@@ -20,8 +20,9 @@ for name, gen, n, k0 in cases:
     t = gen(n)
     L = 32 if name.endswith("L32") else 0
     res = {}
-    for mode in ("1", "0"):
-        os.environ["SA_HIP_NARROW"] = mode
+    for mode in ("1", "t0", "0"):
+        os.environ["SA_HIP_NARROW"] = "0" if mode == "0" else "1"
+        os.environ["SA_HIP_TEXT_PASS"] = "0" if mode == "t0" else "1"
         if k0: os.environ["SA_HIP_INITIAL_CHARS"] = str(k0)
         else: os.environ.pop("SA_HIP_INITIAL_CHARS", None)
         with _capi.DeviceIndex(t.size, 0) as idx:
@@ -33,8 +34,8 @@ for name, gen, n, k0 in cases:
             print("%-8s n=%-10d L=%-2d narrow=%s total %7.2f ms radix %7.2f ms passes %2d bytes/rec %.1f k0=%d b=%d verify=%d" % (
                 name, n, L, mode, st["total_ms"], st["radix_ms"], st["radix_passes"], st["radix_bytes"] / n, st["initial_chars"],
                 st["bits_per_symbol"], bad), flush=True)
-    same = np.array_equal(res["1"][0], res["0"][0])
+    same = np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["t0"][0], res["0"][0])
     print("   same SA:", same, flush=True)
-    ok &= same and res["1"][2] == 0 and res["0"][2] == 0
+    ok &= same and res["1"][2] == 0 and res["0"][2] == 0 and res["t0"][2] == 0
 print("ALL OK" if ok else "FAILED")
 sys.exit(0 if ok else 1)

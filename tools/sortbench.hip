@@ -68,7 +68,38 @@ __global__ __launch_bounds__(512) void copy_tile_kernel(const u64* __restrict__ 
     for (int j = 0; j < 16; ++j) { const u64 i = base + j * 512 + threadIdx.x; if (i < n) vo[i] = vv[j]; }
 }
 
-template <int BLOCK, int ABL, int VER = 1, int OPT = 0>
+// narrow-record shapes: (u32 key, u32 value) tiles; LD16: 16-byte loads (4 records per lane), ST16: 16-byte stores
+template <bool LD16, bool ST16>
+__global__ __launch_bounds__(512) void copy_tile32_kernel(const u32* __restrict__ k, const u32* __restrict__ v, u32* __restrict__ ko,
+                                                          u32* __restrict__ vo, u32 n) {
+    const u64 base = (u64)blockIdx.x * 8192;
+    if (base + 8192 > n) return;   // full tiles only (timing)
+    u32 kk[16], vv[16];
+    if (LD16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint4 x = *reinterpret_cast<const uint4*>(k + base + (j * 512 + threadIdx.x) * 4); kk[4*j] = x.x; kk[4*j+1] = x.y; kk[4*j+2] = x.z; kk[4*j+3] = x.w; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint4 x = *reinterpret_cast<const uint4*>(v + base + (j * 512 + threadIdx.x) * 4); vv[4*j] = x.x; vv[4*j+1] = x.y; vv[4*j+2] = x.z; vv[4*j+3] = x.w; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) kk[j] = k[base + j * 512 + threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) vv[j] = v[base + j * 512 + threadIdx.x];
+    }
+    if (ST16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(ko + base + (j * 512 + threadIdx.x) * 4) = make_uint4(kk[4*j], kk[4*j+1], kk[4*j+2], kk[4*j+3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(vo + base + (j * 512 + threadIdx.x) * 4) = make_uint4(vv[4*j], vv[4*j+1], vv[4*j+2], vv[4*j+3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ko[base + j * 512 + threadIdx.x] = kk[j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) vo[base + j * 512 + threadIdx.x] = vv[j];
+    }
+}
+
+template <int BLOCK, int ABL>
 float run_pass(RadixWorkspace& ws, hipStream_t st, u64* k0, u32* v0, u64* k1, u32* v1, u32 n, int shift, int reps, int home_mode = 0, u32 incl_mask = SA_INCL_MASK) {
     SortGeom g = make_geom(n, BLOCK * SORT_ITEMS);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -130,6 +161,17 @@ int main(int argc, char** argv) {
         COPYV("uint4 x8 nt, grid 1024", (copy16u_kernel<8, true><<<1024, 256, 0, st>>>((const uint4*)k0, (uint4*)k1, nk), copy16u_kernel<8, true><<<1024, 256, 0, st>>>((const uint4*)v0, (uint4*)v1, nv)))
         COPYV("uint4 x4, one span per block", (copy16u_kernel<4, false><<<(unsigned)((nk + 1023) / 1024), 256, 0, st>>>((const uint4*)k0, (uint4*)k1, nk), copy16u_kernel<4, false><<<(unsigned)((nv + 1023) / 1024), 256, 0, st>>>((const uint4*)v0, (uint4*)v1, nv)))
         COPYV("tile shape (8 B + 4 B per lane)", (copy_tile_kernel<<<(n + 8191) / 8192, 512, 0, st>>>(k0, v0, k1, v1, n)))
+    }
+    {   // 8-byte records (u32 key + u32 value): what do 4-byte-per-lane accesses cost?
+        const double gb8 = (double)n * 16.0 / 1e9;
+#define COPY32(name, LD, ST) { hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); float best = 1e9f; \
+        for (int r = 0; r < 5; ++r) { CK(hipEventRecord(e0, st)); copy_tile32_kernel<LD, ST><<<n / 8192, 512, 0, st>>>((const u32*)k0, v0, (u32*)k1, v1, n); \
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms; } \
+        printf("copy32 %-34s %8.3f ms  %7.1f GB/s\n", name, best, gb8 / best * 1e3); fflush(stdout); }
+        COPY32("4 B loads, 4 B stores", false, false)
+        COPY32("16 B loads, 4 B stores", true, false)
+        COPY32("4 B loads, 16 B stores", false, true)
+        COPY32("16 B loads, 16 B stores", true, true)
     }
     // calibration launches for the PMC counters (known byte counts at the kernel's access widths)
     copy8_kernel<<<4096, 256, 0, st>>>(k0, k1, (u64)n);
