@@ -121,7 +121,15 @@ __global__ __launch_bounds__(BLOCK) void seg_hist_kernel(const u32* __restrict__
         const u32 start = plan->bstart[b] + ((f - s_t[b]) * TILE);
         const u32 end = plan->bstart[b + 1];
         const u32 len = (end - start) < TILE ? (end - start) : TILE;
-        for (u32 l = threadIdx.x; l < len; l += BLOCK) atomicAdd(&my[(keys[start + l] >> shift) & mask], 1u);
+        if (len == TILE) {   // all loads of the tile in flight before the first LDS atomic
+            u32 k[SORT_ITEMS];
+#pragma unroll
+            for (int j = 0; j < SORT_ITEMS; ++j) k[j] = keys[start + j * BLOCK + threadIdx.x];
+#pragma unroll
+            for (int j = 0; j < SORT_ITEMS; ++j) atomicAdd(&my[(k[j] >> shift) & mask], 1u);
+        } else {
+            for (u32 l = threadIdx.x; l < len; l += BLOCK) atomicAdd(&my[(keys[start + l] >> shift) & mask], 1u);
+        }
     }
     flush(cur);
 }
@@ -340,6 +348,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024) ? 8 : 4) void seg_onesweep_k
 // thread owns 16 consecutive positions (one 16-byte load + the next one for the c8 - 1 characters that
 // follow), rolls a c8-character window over them and counts into one of TOP_HIST_COPIES LDS histograms.
 constexpr int TOP_HIST_COPIES = 8;
+template <int C8>   // characters that make up the top 8 key bits: ceil(8 / b), a compile-time constant so that the window loop unrolls
 __global__ __launch_bounds__(256) void top_hist_kernel(const u8* __restrict__ text, const u16* __restrict__ map, u64 n, int b,
                                                        SortGeom g, u32* __restrict__ hist) {
     constexpr int CS = RADIX + 1;
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(256) void top_hist_kernel(const u8* __restrict__ te
     for (int i = threadIdx.x; i < TOP_HIST_COPIES * CS; i += 256) s_h[i] = 0;
     __syncthreads();
     u32* my = s_h + (threadIdx.x & (TOP_HIST_COPIES - 1)) * CS;
-    const int c8 = (8 + b - 1) / b;
+    constexpr int c8 = C8;
     const u32 wmask = (1u << (c8 * b)) - 1u;
     const int dshift = c8 * b - 8;
     const u64 nspans = (n + SPAN - 1) / SPAN;
@@ -380,8 +389,7 @@ __global__ __launch_bounds__(256) void top_hist_kernel(const u8* __restrict__ te
             const u32 live = (n - p0 < 32) ? (u32)(n - p0) : 32u;   // bytes of the text among the 32
             u32 win = 0;
 #pragma unroll
-            for (int k = 0; k < 16 + 7; ++k) {
-                if (k >= 16 + c8 - 1) break;
+            for (int k = 0; k < 16 + c8 - 1; ++k) {
                 const u32 byte = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
                 const u32 code = ((u32)k < live) ? (u32)s_map[byte] : 0u;
                 win = ((win << b) | code) & wmask;
@@ -565,8 +573,9 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
     }
 }
 
+// 79 VGPRs and 50 KB of LDS: three workgroups (24 waves) per CU
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, 4) void text_top_pass_kernel(TextPassArgs a) {
+__global__ __launch_bounds__(BLOCK, 6) void text_top_pass_kernel(TextPassArgs a) {
     constexpr int WAVES = BLOCK / WAVE;
     constexpr u32 TILE = BLOCK * SORT_ITEMS;
     __shared__ __attribute__((aligned(16))) u32 s_keys[TILE];
@@ -658,7 +667,14 @@ inline int narrow_text_histogram(RadixWorkspace& ws, NarrowWorkspace& nw, hipStr
     SA_HIP_CHECK(hipMemcpyAsync(nw.map_dev, nw.map_host.code, sizeof(CodeMap), hipMemcpyHostToDevice, stream));
     const SortGeom g = make_geom(n, ws.tile());
     const u32 spans = div_up(n, 4096);
-    hipLaunchKernelGGL(top_hist_kernel, dim3(spans < 2048u ? spans : 2048u), dim3(256), 0, stream, text, nw.map_dev, (u64)n, b, g, ws.hist(0));
+    const dim3 grid(spans < 2048u ? spans : 2048u), block(256);
+    switch ((8 + b - 1) / b) {
+        case 1: hipLaunchKernelGGL(top_hist_kernel<1>, grid, block, 0, stream, text, nw.map_dev, (u64)n, b, g, ws.hist(0)); break;
+        case 2: hipLaunchKernelGGL(top_hist_kernel<2>, grid, block, 0, stream, text, nw.map_dev, (u64)n, b, g, ws.hist(0)); break;
+        case 3: hipLaunchKernelGGL(top_hist_kernel<3>, grid, block, 0, stream, text, nw.map_dev, (u64)n, b, g, ws.hist(0)); break;
+        case 4: hipLaunchKernelGGL(top_hist_kernel<4>, grid, block, 0, stream, text, nw.map_dev, (u64)n, b, g, ws.hist(0)); break;
+        default: hipLaunchKernelGGL(top_hist_kernel<8>, grid, block, 0, stream, text, nw.map_dev, (u64)n, b, g, ws.hist(0)); break;
+    }
     return 0;
 }
 
