@@ -45,7 +45,7 @@ def usable_cpus():
 
 
 PASS_KERNELS = ["radix_onesweep_kernel<512, 0, false>", "radix_onesweep_kernel<512, 0, true>",
-                "seg_onesweep_kernel<512, false>", "seg_onesweep_kernel<512, true>"]   # sa_hip_build_stats.pass_*
+                "seg_onesweep_kernel<512, 16, false>", "seg_onesweep_kernel<512, 16, true>"]   # sa_hip_build_stats.pass_*
 
 
 def pmc_traffic(n, kernel):
@@ -222,6 +222,8 @@ def main():
         steps = args.steps
         chars_per_s = world * N * steps / (build_ms_max / 1e3)          # replicas: every rank builds N chars
         queries_per_s = world * Q * steps / (query_ms_max / 1e3)
+        if last.get("text_top_pass"):
+            PASS_KERNELS[1] = "text_top_pass_kernel<512>"
         # dominant kernel = the sort-pass kernel with the largest share of the timed region
         dom = max(range(4), key=lambda k: kind_ms[k])
         pass_ms = kind_ms[dom] / max(kind_launches[dom], 1)

@@ -164,12 +164,15 @@ typedef struct sa_hip_build_stats {
     double   radix_ms;           /* HIP-event time of all onesweep launches                */
     double   total_ms;           /* HIP-event time of the whole device build               */
     /* the sort passes by kernel: [0] radix_onesweep_kernel<512> (u64 key + u32 value in and out),
-     * [1] the same with narrow output (top digit of a narrow sort: u32 key + u32 value out),
-     * [2] seg_onesweep_kernel<512,false> (u32 key + u32 value in and out),
-     * [3] seg_onesweep_kernel<512,true> (u32 key + u32 value in, u64 key + u32 value out) */
+     * [1] top digit of a narrow sort (u32 key + u32 value out): radix_onesweep_kernel<512,0,true> from u64
+     *     keys, or text_top_pass_kernel<512> from the text (text_top_pass),
+     * [2] seg_onesweep_kernel<512,16,false> (u32 key + u32 value in and out),
+     * [3] seg_onesweep_kernel<512,16,true> (u32 key + u32 value in, u64 key + u32 value out) */
     double   pass_ms[4];
     uint64_t pass_bytes[4];      /* algorithmic bytes (read + written)                      */
     uint32_t pass_launches[4];
+    uint32_t text_top_pass;      /* 1: kernel [1] was text_top_pass_kernel<512> (keys assembled from the text) */
+    uint32_t reserved_;
 } sa_hip_build_stats;
 int sa_hip_index_build_stats(const sa_hip_index* idx, sa_hip_build_stats* out);
 

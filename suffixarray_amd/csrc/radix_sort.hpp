@@ -22,13 +22,15 @@
 //   1. takes the next tile of a chunk from that chunk's atomic ticket (tiles of a chunk start in
 //      ticket order, so every predecessor is already resident -> look-back cannot deadlock),
 //   2. loads its tile wave-striped (64 lanes x 8 B = 512 B per load instruction),
-//   3. ranks its keys per wave with __ballot match masks (64-wide; 8 ballots per key) and
-//      per-wave digit counters in LDS -- no LDS atomics, stable by construction,
+//   3. ranks its keys per wave with ballot match masks (wave_rank: 64-wide; per digit bit one
+//      v_bfe_i32, one v_cmp and two v_bitop3) and per-wave digit counters in LDS -- no LDS
+//      atomics, stable by construction,
 //   4. publishes its 256 digit counts as 8-byte {epoch,flag,count} granules (one relaxed
 //      agent-scope store each; the data IS the flag, cdna_hip_programming.md G16/R2), reorders
 //      its keys through LDS, then resolves its exclusive prefix by decoupled look-back over the
-//      predecessor tiles of its chunk, LB_WINDOW polls in flight per lane (relaxed agent-scope
-//      loads; every spin is bounded and sets DeviceStatus.error),
+//      predecessor tiles of its chunk, SA_LB_WINDOW polls in flight per lane (relaxed agent-scope
+//      loads; every spin is bounded and sets DeviceStatus.error); only every 4th tile publishes
+//      its inclusive prefix as well (SA_INCL_MASK),
 //   5. streams keys (then values) out of LDS so that each digit's run leaves the CU as contiguous
 //      global stores, counting the next pass's (chunk, digit) histogram on the way.
 // Algorithmic bytes per pass over M records: 2*M*(8+4).

@@ -1167,6 +1167,7 @@ struct Builder {
         // the narrow sort starts with the TOP digit, the plain LSD sort with the lowest one; when the top-digit
         // pass reads the text itself, key generation shrinks to the histogram of that digit
         const bool text_pass = narrow_path && text_top_pass && text_pass_applies(b, k0);
+        stats.text_top_pass = text_pass ? 1u : 0u;
         if (text_pass) {
             if ((rc = narrow_text_histogram(radix, narrow, stream, text.as<u8>(), map, n32, b))) return rc;
         } else {
