@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void seg_plan_kernel(const u32* __restrict__ h
     u32 size = 0;
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) size += hist_top[c * RADIX + d];
-    const u32 tiles = (size + (1u << tile_shift) - 1) >> tile_shift;
+    const u32 tiles = (u32)(((u64)size + (1u << tile_shift) - 1) >> tile_shift);
     u32 is = size, it = tiles;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {

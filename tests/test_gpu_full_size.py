@@ -116,16 +116,24 @@ def test_long_repeats_67m_many_doubling_rounds(gpu):
             assert idx.verify() == 0, st
 
 
-def test_beyond_int32_max_3e9_verified(gpu):
+def test_beyond_int32_max_3e9_verified(gpu, monkeypatch):
     """n = 3e9 > INT32_MAX: past the reach of 32-bit libsais (the reference switches to the true
     64-bit libsais64 there, libsais64.c:6684); the device pipeline keeps unsigned 32-bit suffix
     indices up to n = 2^32 - 2.  Checked by the on-device sufcheck and text spot checks of queries."""
     from suffixarray_amd import synth
     n = 3_000_000_000
     t = synth.d1_uniform27(n)
+    # both sort plans beyond 2^31 records: the build's own choice (40-bit keys in narrow records: positions and
+    # bucket offsets above INT32_MAX), then the 12-byte-record plan
     with gpu.DeviceIndex(n, 0) as idx:
         idx.build(t)
-        assert idx.verify() == 0, idx.build_stats()
+        st = idx.build_stats()
+        assert st["pass_launches"][2] > 0 and idx.verify() == 0, st
+    monkeypatch.setenv("SA_HIP_NARROW", "0")
+    with gpu.DeviceIndex(n, 0) as idx:
+        idx.build(t)
+        st = idx.build_stats()
+        assert st["pass_launches"][0] > 0 and idx.verify() == 0, st
         buf, off = synth.query_batch(t, 20000, 16)
         got = idx.query_batch((buf, off))
         pats = buf.reshape(-1, 16)
