@@ -292,8 +292,8 @@ __device__ __forceinline__ void seg_tile(const SegPassArgs& a, const u32 flat, c
     }
 }
 
-// BLOCK x ITEMS = 512 x 16 (4 waves per SIMD at <= 128 VGPRs) or 1024 x 8 (8 waves per SIMD at <= 64): the same
-// 8192-record tile and the same LDS either way, twice the waves to hide the ranking and look-back chains
+// BLOCK x ITEMS = 512 x 16 (102 VGPRs, 4 waves per SIMD).  1024 x 8 (64 VGPRs, 8 waves per SIMD, the same 8192-record
+// tile and LDS) was measured at the same speed (3.76 vs 3.78 ms per pass at N = 1e9) and is not instantiated.
 template <int BLOCK, int ITEMS, bool LAST>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 1024) ? 8 : 4) void seg_onesweep_kernel(SegPassArgs a) {
     constexpr int WAVES = BLOCK / WAVE;
@@ -621,12 +621,10 @@ struct NarrowWorkspace {
     u32* hist = nullptr;     // [NARROW_MAX_PASSES][RADIX][RADIX]
     u32* base = nullptr;     // [RADIX][RADIX]
     u32* tickets = nullptr;  // [NARROW_MAX_PASSES][NCHUNK]
-    bool wide_block = false; // SA_HIP_NARROW_BLOCK=1024: 1024 x 8 workgroups instead of 512 x 16
     u16* map_dev = nullptr;  // CodeMap of the text pass
     CodeMap map_host;        // source of the asynchronous copy (must outlive the call)
     static size_t hist_bytes() { return (size_t)NARROW_MAX_PASSES * RADIX * RADIX * sizeof(u32); }
     int init() {
-        if (const char* e = getenv("SA_HIP_NARROW_BLOCK")) wide_block = atoi(e) == 1024;
         SA_HIP_CHECK(hipMalloc(&plan, sizeof(SegPlan)));
         SA_HIP_CHECK(hipMalloc(&hist, hist_bytes()));
         SA_HIP_CHECK(hipMalloc(&base, (size_t)RADIX * RADIX * sizeof(u32)));
@@ -678,9 +676,11 @@ inline int narrow_text_histogram(RadixWorkspace& ws, NarrowWorkspace& nw, hipStr
     return 0;
 }
 
-// Sort n records (keysA[i], i) by key bits [begin_bit, 64), stable.  src != nullptr: keysA holds nothing yet,
-// the keys are the first src->k0 characters of every text position (ws.hist(0) must be ready: narrow_text_histogram).  keysA holds the u64 keys and the
-// histogram of their top digit has been accumulated into ws.hist(0) by the producer (radix_prepare() before).
+// Sort n records (key[i], i) by key bits [begin_bit, 64), stable.
+//   src == nullptr: keysA holds the u64 keys and the per-chunk histogram of their top digit has been accumulated
+//                   into ws.hist(0) by the producer (radix_prepare() before, keygen_kernel);
+//   src != nullptr: keysA holds nothing yet, the keys are the first src->k0 characters of every text position
+//                   (radix_prepare() + narrow_text_histogram() before).
 // keysA / keysB and valsA / valsB are the ping-pong buffers of the plain sort (n * 8 and n * 4 bytes);
 // narrow keys use the first n * 4 bytes of a key buffer.  Result: *keys_res (u64, full keys), *vals_res.
 inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_t stream, u64* keysA, u32* valsA, u64* keysB,
@@ -692,7 +692,8 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
     SA_HIP_CHECK(hipMemsetAsync(nw.hist, 0, NarrowWorkspace::hist_bytes(), stream));
     SA_HIP_CHECK(hipMemsetAsync(nw.tickets, 0, (size_t)NARROW_MAX_PASSES * NCHUNK * sizeof(u32), stream));
 
-    // top digit: ordinary one-sweep pass, values generated, keys leave as their low bits
+    // top digit: values generated, keys leave as their low bits -- from the text, or from the u64 key array by the
+    // ordinary one-sweep pass
     {
         if (++ws.epoch >= (1u << 30)) {
             SA_HIP_CHECK(hipMemsetAsync(ws.status, 0, (size_t)ws.max_tiles * RADIX * sizeof(u64), stream));
@@ -709,16 +710,16 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
             if ((rc = ws.timer.stop(stream, (u64)n * 9u))) return rc;
             ws.pass_records += n; ws.pass_bytes += (u64)n * 9u; ws.passes += 1;
         } else {
-        SortPassArgs a;
-        a.keys_in = keysA; a.vals_in = nullptr; a.keys_out = nullptr; a.vals_out = valsB;
-        a.g = g; a.shift = 56; a.mask = 255u; a.next_shift = -1; a.next_mask = 0; a.digit_base = ws.base();
-        a.next_hist = nullptr; a.status = ws.status; a.ticket = ws.tickets(); a.epoch = ws.epoch; a.dstat = ws.dstat;
-        a.home_mode = 0; a.incl_mask = SA_INCL_MASK;
-        a.keys_out32 = reinterpret_cast<u32*>(keysB); a.narrow_shift = begin_bit;
-        if ((rc = ws.timer.start(stream, 1))) return rc;
-        hipLaunchKernelGGL((radix_onesweep_kernel<512, 0, true>), dim3(g.tiles), dim3(512), 0, stream, a);
-        if ((rc = ws.timer.stop(stream, (u64)n * 16u))) return rc;
-        ws.pass_records += n; ws.pass_bytes += (u64)n * 16u; ws.passes += 1;
+            SortPassArgs a;
+            a.keys_in = keysA; a.vals_in = nullptr; a.keys_out = nullptr; a.vals_out = valsB;
+            a.g = g; a.shift = 56; a.mask = 255u; a.next_shift = -1; a.next_mask = 0; a.digit_base = ws.base();
+            a.next_hist = nullptr; a.status = ws.status; a.ticket = ws.tickets(); a.epoch = ws.epoch; a.dstat = ws.dstat;
+            a.home_mode = 0; a.incl_mask = SA_INCL_MASK;
+            a.keys_out32 = reinterpret_cast<u32*>(keysB); a.narrow_shift = begin_bit;
+            if ((rc = ws.timer.start(stream, 1))) return rc;
+            hipLaunchKernelGGL((radix_onesweep_kernel<512, 0, true>), dim3(g.tiles), dim3(512), 0, stream, a);
+            if ((rc = ws.timer.stop(stream, (u64)n * 16u))) return rc;
+            ws.pass_records += n; ws.pass_bytes += (u64)n * 16u; ws.passes += 1;
         }
     }
     hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(256), 0, stream, ws.hist(0), g.tile_shift, nw.plan);
@@ -751,15 +752,10 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
         a.digit_base = nw.base;
         a.next_hist = last ? nullptr : nw.hist + (size_t)(p + 1) * RADIX * RADIX;
         a.status = ws.status; a.ticket = nw.tickets + p * NCHUNK; a.epoch = ws.epoch; a.dstat = ws.dstat;
-        a.lo_shift = begin_bit; a.incl_mask = SA_INCL_MASK;
+        a.lo_shift = begin_bit; a.incl_mask = SA_INCL_MASK;   // every 4th tile: 1 / 3 / 7 / 15 measured 3.84 / 3.74 / 3.80 / 3.98 ms per pass
         if ((rc = ws.timer.start(stream, last ? 3 : 2))) return rc;
-        if (nw.wide_block) {
-            if (last) hipLaunchKernelGGL((seg_onesweep_kernel<1024, 8, true>), dim3(flat_max), dim3(1024), 0, stream, a);
-            else hipLaunchKernelGGL((seg_onesweep_kernel<1024, 8, false>), dim3(flat_max), dim3(1024), 0, stream, a);
-        } else {
-            if (last) hipLaunchKernelGGL((seg_onesweep_kernel<512, 16, true>), dim3(flat_max), dim3(512), 0, stream, a);
-            else hipLaunchKernelGGL((seg_onesweep_kernel<512, 16, false>), dim3(flat_max), dim3(512), 0, stream, a);
-        }
+        if (last) hipLaunchKernelGGL((seg_onesweep_kernel<512, 16, true>), dim3(flat_max), dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((seg_onesweep_kernel<512, 16, false>), dim3(flat_max), dim3(512), 0, stream, a);
         if ((rc = ws.timer.stop(stream, (u64)n * (last ? 20u : 16u)))) return rc;
         ws.pass_records += n; ws.pass_bytes += (u64)n * (last ? 20u : 16u); ws.passes += 1;
         u32* tk = kin; kin = kout; kout = tk;

@@ -32,15 +32,14 @@ __device__ __forceinline__ u64 load_be64(const u8* p) {
     return __builtin_bswap64(v);
 }
 
-// big-endian word j of the pattern, zero padded past c
+// big-endian word j of the pattern, zero padded past c: one 8-byte load for a whole word, byte loads only
+// for the last partial word (nothing past the pattern's end is touched)
 __device__ __forceinline__ u64 pattern_word(const u8* q, u32 c, u32 j) {
-    u64 v = 0;
     const u32 o = j * 8;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const u32 i = o + k;
-        v = (v << 8) | (u64)((i < c) ? q[i] : 0);
-    }
+    if (o >= c) return 0ull;
+    if (c - o >= 8) return load_be64(q + o);
+    u64 v = 0;
+    for (u32 k = 0; k < 8; ++k) v = (v << 8) | (u64)((o + k < c) ? q[o + k] : 0);
     return v;
 }
 
@@ -149,7 +148,13 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
 
         // ---- phase 2: text comparisons inside [lo, hi) ---------------------------------------------
         u64 lb = lo, ub = hi;
-        if (!exact) {
+        if (!exact && hi - lo == 1) {
+            // one candidate slot (the usual case once K has resolved the first k0 characters): one compare
+            // settles both bounds
+            const int r = cmp_suffix<4>(a.text, a.n, a.sa[lo], qw, q, c);
+            lb = (r < 0) ? hi : lo;
+            ub = (r > 0) ? lo : hi;
+        } else if (!exact) {
             u64 l = lo, h = hi, h_strict = hi;
             while (l < h) {
                 const u64 mid = (l + h) >> 1;
