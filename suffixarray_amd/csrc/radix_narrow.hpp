@@ -182,6 +182,9 @@ __device__ __forceinline__ void seg_tile(const SegPassArgs& a, const u32 flat, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 woff = (u32)wave * (WAVE * ITEMS) + lane;
 
+    // this digit's base inside the bucket: requested now, needed after the look-back
+    const u32 dbase = (tid < RADIX) ? a.digit_base[bucket * RADIX + tid] : 0u;
+
     // 1. load (wave-striped)
     u32 key[ITEMS];
     const u32* kin = a.keys_in + start;
@@ -254,7 +257,7 @@ __device__ __forceinline__ void seg_tile(const SegPassArgs& a, const u32 flat, c
                 __hip_atomic_store(&a.status[(u64)flat * RADIX + tid], pack_status(a.epoch, FLAG_INCL, prefix + count),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        s_gdelta[tid] = a.digit_base[bucket * RADIX + tid] + prefix - excl;
+        s_gdelta[tid] = dbase + prefix - excl;
     }
     __syncthreads();
 
@@ -304,6 +307,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024) ? 8 : 4) void seg_onesweep_k
     __shared__ u32 s_gdelta[RADIX];
     __shared__ u32 s_wsum[RADIX / WAVE];
     __shared__ u32 s_t[RADIX + 1];
+    __shared__ u32 s_b[RADIX + 1];
     __shared__ u32 s_c[NCHUNK + 1];
     __shared__ u32 s_flat;
 
@@ -314,7 +318,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024) ? 8 : 4) void seg_onesweep_k
         home = xcc_id();
         t_home = atomicAdd(&a.ticket[home], 1u);
     }
-    for (int i = tid; i <= RADIX; i += BLOCK) s_t[i] = a.plan->tprefix[i];
+    // the whole plan goes to LDS while the ticket is in flight: no dependent global load between the ticket and
+    // the tile's first key load
+    for (int i = tid; i <= RADIX; i += BLOCK) { s_t[i] = a.plan->tprefix[i]; s_b[i] = a.plan->bstart[i]; }
     if (tid <= NCHUNK) s_c[tid] = a.plan->cfirst[tid];
     for (int i = tid; i < WAVES * RADIX; i += BLOCK) s_whist[i] = 0;
     __syncthreads();
@@ -335,8 +341,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024) ? 8 : 4) void seg_onesweep_k
     if (flat == 0xFFFFFFFFu) return;   // block-uniform
     const u32 bucket = seg_bucket_of(s_t, flat);
     const u32 first_flat = s_t[bucket];
-    const u32 start = a.plan->bstart[bucket] + (flat - first_flat) * TILE;
-    const u32 rest = a.plan->bstart[bucket + 1] - start;
+    const u32 start = s_b[bucket] + (flat - first_flat) * TILE;
+    const u32 rest = s_b[bucket + 1] - start;
     if (rest >= TILE)
         seg_tile<true, BLOCK, ITEMS, LAST>(a, flat, first_flat, bucket, start, TILE, s_keys, s_whist, s_gdelta, s_wsum);
     else
@@ -438,6 +444,8 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
     const u32 first_tile = chunk * a.g.tpc;
     const u64 tile_base = (u64)tile * TILE;
     const u32 woff = (u32)wave * (WAVE * ITEMS) + lane;
+
+    const u32 dbase = (tid < RADIX) ? a.digit_base[chunk * RADIX + tid] : 0u;   // needed after the look-back
 
     // 0. text -> codes in LDS: 16 bytes per thread, the halo by the first TEXT_HALO / 16 threads
     //    (the text buffer is readable for TEXT_PAD >= 16 bytes past n; a load starts below n or is skipped)
@@ -546,7 +554,7 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
                 __hip_atomic_store(&a.status[(u64)tile * RADIX + tid], pack_status(a.epoch, FLAG_INCL, prefix + count),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        s_gdelta[tid] = a.digit_base[chunk * RADIX + tid] + prefix - excl;
+        s_gdelta[tid] = dbase + prefix - excl;
     }
     __syncthreads();
 

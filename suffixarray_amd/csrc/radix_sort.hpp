@@ -294,6 +294,9 @@ __device__ __forceinline__ void onesweep_tile(const SortPassArgs& a, const u32 t
     const u64 tile_base = (u64)tile * TILE;
     const u32 woff = (u32)wave * (WAVE * SORT_ITEMS) + lane;   // tile-local index of this lane's record 0
 
+    // this digit's global base for the chunk: requested now, needed after the look-back
+    const u32 dbase = (tid < RADIX) ? a.digit_base[chunk * RADIX + tid] : 0u;
+
     // 1. load (wave-striped): wave w owns records [w*64*ITEMS, (w+1)*64*ITEMS) of the tile
     u64 key[SORT_ITEMS];
     const u64* kin = a.keys_in + tile_base;
@@ -380,7 +383,7 @@ __device__ __forceinline__ void onesweep_tile(const SortPassArgs& a, const u32 t
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // this digit's run occupies global positions [g0, g0 + count); gdelta maps tile-local -> global
-        const u32 g0 = a.digit_base[chunk * RADIX + tid] + prefix;
+        const u32 g0 = dbase + prefix;
         const u32 gdelta = g0 - excl;
         // destination chunk of the run's records: c0, or c0 + 1 from tile-local position thr on
         // (a run is at most one tile long and a chunk at least one tile, so one boundary at most)

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
             int sh = 64;
             const int pmax = (c < (u32)a.k0) ? (int)c : a.k0;
             for (; P < pmax; ++P) {
-                const u32 code = s_map[q[P]];
+                const u32 byte = (P < 32) ? (u32)(qw[P >> 3] >> (56 - 8 * (P & 7))) & 255u : (u32)q[P];   // pattern bytes are in qw already
+                const u32 code = s_map[byte];
                 if (code == 0) break;   // byte absent from the text: nothing matches past here
                 sh -= a.b;
                 key_lo |= (u64)code << sh;
