@@ -128,7 +128,9 @@ def test_narrow_record_sort_matches_plain_sort(gpu, oracle, monkeypatch):
     skew = rng.choice(np.array([97, 98, 99, 100, 122], dtype=np.uint8), 6_000_000, p=[0.9, 0.04, 0.03, 0.02, 0.01])
     two = rng.choice(np.array([97, 122], dtype=np.uint8), 5_000_000)
     runs = [(synth.d1_uniform27(4_500_001), 0, 0), (synth.d1_uniform27(6_000_000), 7, 0), (synth.d1_uniform27(5_000_000), 0, 32),
-            (skew, 13, 0), (skew, 9, 0), (two, 20, 0), (two, 9, 6), (synth.d2_words(8_000_000), 8, 0)]
+            (skew, 13, 0), (skew, 9, 0), (two, 20, 0), (two, 9, 6), (synth.d2_words(8_000_000), 8, 0),
+            # 256 symbols: 9-bit codes, the top-digit pass reads u64 keys (radix_onesweep_kernel<512,0,true>), not the text
+            (rng.integers(0, 256, 5_000_000).astype(np.uint8), 0, 4)]
     for t, k0, L in runs:
         if k0:
             monkeypatch.setenv("SA_HIP_INITIAL_CHARS", str(k0))

@@ -29,6 +29,24 @@ def test_struct_layouts_match_reference_abi(capi):
     assert C.sizeof(capi.PairU32) == 8              # engine.h:219-222
 
 
+def test_stats_structs_match_the_header(capi, tmp_path):
+    """The ctypes mirrors of the instrumentation structs against the C compiler's view of include/sa_hip.h."""
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sa_hip.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(sa_hip_build_stats), offsetof(sa_hip_build_stats, radix_ms),'
+                   ' offsetof(sa_hip_build_stats, pass_ms), offsetof(sa_hip_build_stats, pass_launches), sizeof(sa_hip_query_stats),'
+                   ' sizeof(sa_hip_csv_column)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    B = capi.BuildStats
+    assert got == [C.sizeof(B), B.radix_ms.offset, B.pass_ms.offset, B.pass_launches.offset, C.sizeof(capi.QueryStats),
+                   C.sizeof(capi.CsvColumn)], got
+
+
 def test_no_gpu_means_loud_failure(capi):
     """Without a device every compute entry point must fail, never fall back."""
     if capi.lib().sa_hip_device_count() >= 1:
