@@ -174,7 +174,7 @@ struct SegPassArgs {
     u32 incl_mask;
 };
 
-template <bool FULL, int BLOCK, int ITEMS, bool LAST>
+template <bool FULL, int BLOCK, int ITEMS, bool LAST, bool LATEV>
 __device__ __forceinline__ void seg_tile(const SegPassArgs& a, const u32 flat, const u32 first_flat, const u32 bucket,
                                          const u32 start, const u32 tile_n, u32* s_keys, u32* s_whist, u32* s_gdelta,
                                          u32* s_wsum) {
@@ -197,13 +197,18 @@ __device__ __forceinline__ void seg_tile(const SegPassArgs& a, const u32 flat, c
     u32 rd[ITEMS];
     u32* wh = s_whist + wave * RADIX;
     wave_rank<FULL>(key, a.shift, a.mask, woff, tile_n, wh, rd);
+    // values: right after the ranking (their latency hides behind the count / look-back phase), or -- LATEV -- only
+    // when they are needed, which keeps 16 registers free through the look-back (three workgroups per CU instead of two)
     u32 val[ITEMS];
     const u32* vin = a.vals_in + start;
+    auto load_vals = [&]() {
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const u32 p = woff + j * WAVE;
-        val[j] = (FULL || p < tile_n) ? vin[p] : 0u;
-    }
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 p = woff + j * WAVE;
+            val[j] = (FULL || p < tile_n) ? vin[p] : 0u;
+        }
+    };
+    if (!LATEV) load_vals();
     __syncthreads();
 
     // 3. tile digit counts -> aggregate -> exclusive scan over digits
@@ -283,6 +288,7 @@ __device__ __forceinline__ void seg_tile(const SegPassArgs& a, const u32 flat, c
             if (v) atomicAdd(&a.next_hist[bucket * RADIX + i], v);
         }
     }
+    if (LATEV) load_vals();
     u32* s_vals = s_keys;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j)
@@ -295,10 +301,13 @@ __device__ __forceinline__ void seg_tile(const SegPassArgs& a, const u32 flat, c
     }
 }
 
-// BLOCK x ITEMS = 512 x 16 (102 VGPRs, 4 waves per SIMD).  1024 x 8 (64 VGPRs, 8 waves per SIMD, the same 8192-record
-// tile and LDS) was measured at the same speed (3.76 vs 3.78 ms per pass at N = 1e9) and is not instantiated.
-template <int BLOCK, int ITEMS, bool LAST>
-__global__ __launch_bounds__(BLOCK, (BLOCK == 1024) ? 8 : 4) void seg_onesweep_kernel(SegPassArgs a) {
+// Occupancy is what this kernel lives on: with the values loaded right after the ranking it needs 104 VGPRs (two
+// workgroups = two tiles in flight per CU); loading them only before they are staged (LATEV) fits 80 VGPRs (3-5 spilled)
+// and, with 44 KB of LDS, THREE workgroups per CU: 3.80-3.86 -> 3.44-3.49 ms per pass at N = 1e9.  It is the number of
+// tiles in flight that counts, not the number of waves: 1024 x 8 threads x records (64 VGPRs, two workgroups of 16 waves)
+// ran at the speed of 512 x 16 with two workgroups (3.76 vs 3.78 ms).
+template <int BLOCK, int ITEMS, bool LAST, bool LATEV = true>
+__global__ __launch_bounds__(BLOCK, LATEV ? 6 : 4) void seg_onesweep_kernel(SegPassArgs a) {
     constexpr int WAVES = BLOCK / WAVE;
     constexpr u32 TILE = BLOCK * ITEMS;
     static_assert(TILE == 512 * SORT_ITEMS, "the plan's tile size");
@@ -344,9 +353,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024) ? 8 : 4) void seg_onesweep_k
     const u32 start = s_b[bucket] + (flat - first_flat) * TILE;
     const u32 rest = s_b[bucket + 1] - start;
     if (rest >= TILE)
-        seg_tile<true, BLOCK, ITEMS, LAST>(a, flat, first_flat, bucket, start, TILE, s_keys, s_whist, s_gdelta, s_wsum);
+        seg_tile<true, BLOCK, ITEMS, LAST, LATEV>(a, flat, first_flat, bucket, start, TILE, s_keys, s_whist, s_gdelta, s_wsum);
     else
-        seg_tile<false, BLOCK, ITEMS, LAST>(a, flat, first_flat, bucket, start, rest, s_keys, s_whist, s_gdelta, s_wsum);
+        seg_tile<false, BLOCK, ITEMS, LAST, LATEV>(a, flat, first_flat, bucket, start, rest, s_keys, s_whist, s_gdelta, s_wsum);
 }
 
 // ---- histogram of the top digit, per chunk of the input order, straight from the text -----------------------
