@@ -441,7 +441,15 @@ struct TextPassArgs {
 };
 constexpr int TEXT_HALO = 64;   // >= k0 - 1 (k0 * b <= 40)
 
-template <bool FULL, int BLOCK>
+// acc |= x << s (s uniform), accumulator updated in place
+__device__ __forceinline__ void shl_or_inplace(u32& acc, u32 x, int s) {
+    asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "s"(s));
+}
+
+// CB, CK0: b and k0 as compile-time constants (0: run-time values of the arguments).  Not instantiated: with b = 5,
+// k0 = 8 as constants the compiler merges a key's eight byte reads into one unaligned ds_read_b64 and the pass
+// gets slower (4.54 vs 3.69 ms at N = 1e9).
+template <bool FULL, int BLOCK, int CB, int CK0>
 __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 tile, const u32 chunk,
                                               const u32 tile_n, u32* s_keys, u32* s_whist, u32* s_gdelta, u32* s_wsum,
                                               u8* s_code, const u8* s_map) {
@@ -482,23 +490,47 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
     u32 hi[ITEMS], lo[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) { hi[j] = 0; lo[j] = 0; }
+    // three loops with ONE body each (characters entirely in the upper word, at most one character that straddles
+    // bit 32, characters entirely in the lower word): a single loop with the three cases as branches made the
+    // compiler shuffle all 32 accumulators through copies on every iteration (64 moves for 16 useful operations);
+    // the accumulate is an in-place v_lshl_or_b32 (as C it is computed into a new register and copied back)
     const u8* cp = s_code + woff;
-    int sh = 64;
-    for (int c = 0; c < a.k0; ++c, ++cp) {
-        sh -= a.b;
-        if (sh >= 32) {
+    if constexpr (CB > 0 && CK0 > 0) {
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) hi[j] |= (u32)cp[j * WAVE] << (sh - 32);
-        } else if (sh + a.b <= 32) {
+        for (int c = 0; c < CK0; ++c) {
+            constexpr int b = CB;
+            const int sh = 64 - b * (c + 1);
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) lo[j] |= (u32)cp[j * WAVE] << sh;
-        } else {   // the character straddles bit 32
+            for (int j = 0; j < ITEMS; ++j) {
+                const u32 code = cp[c + j * WAVE];
+                if (sh >= 32) hi[j] |= code << (sh - 32);
+                else {
+                    lo[j] |= code << sh;
+                    if (sh + b > 32) hi[j] |= code >> (32 - sh);
+                }
+            }
+        }
+    } else {
+        int c = 0;
+        for (; c < a.k0 && 64 - a.b * (c + 1) >= 32; ++c, ++cp) {
+            const int s_hi = 32 - a.b * (c + 1);
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) shl_or_inplace(hi[j], (u32)cp[j * WAVE], s_hi);
+        }
+        if (c < a.k0 && 64 - a.b * c > 32) {
+            const int sh = 64 - a.b * (c + 1);   // 0 < sh < 32 < sh + b
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
                 const u32 code = cp[j * WAVE];
                 hi[j] |= code >> (32 - sh);
                 lo[j] |= code << sh;
             }
+            ++c; ++cp;
+        }
+        for (; c < a.k0; ++c, ++cp) {
+            const int sh = 64 - a.b * (c + 1);
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) shl_or_inplace(lo[j], (u32)cp[j * WAVE], sh);
         }
     }
     u32 key[ITEMS];   // narrow keys: bits [begin_bit, begin_bit + 32) of hi:lo
@@ -591,7 +623,7 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
 }
 
 // 79 VGPRs and 50 KB of LDS: three workgroups (24 waves) per CU
-template <int BLOCK>
+template <int BLOCK, int CB = 0, int CK0 = 0>
 __global__ __launch_bounds__(BLOCK, 6) void text_top_pass_kernel(TextPassArgs a) {
     constexpr int WAVES = BLOCK / WAVE;
     constexpr u32 TILE = BLOCK * SORT_ITEMS;
@@ -627,9 +659,9 @@ __global__ __launch_bounds__(BLOCK, 6) void text_top_pass_kernel(TextPassArgs a)
     const u32 chunk = s_chunk;
     const u64 rest = a.n - (u64)tile * TILE;
     if (rest >= (u64)TILE)
-        text_top_tile<true, BLOCK>(a, tile, chunk, TILE, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
+        text_top_tile<true, BLOCK, CB, CK0>(a, tile, chunk, TILE, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
     else
-        text_top_tile<false, BLOCK>(a, tile, chunk, (u32)rest, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
+        text_top_tile<false, BLOCK, 0, 0>(a, tile, chunk, (u32)rest, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
 }
 
 // ---- host driver --------------------------------------------------------------------------------------
