@@ -824,6 +824,7 @@ struct Builder {
     sa_hip_build_stats stats;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int chunk_rounds_before_doubling = 2;
+    bool adaptive_doubling = true;    // SA_HIP_ADAPTIVE_DOUBLING: more chunk rounds while the active set halves
     int initial_chars_override = 0;   // SA_HIP_INITIAL_CHARS: 0 = heuristic
     double pilot_dup_share = 0.0;     // share of sampled 8-byte windows seen before (pilot_kernel)
     DevBuf pilot;
@@ -878,6 +879,7 @@ struct Builder {
         if (const char* e = getenv("SA_HIP_SORT_BLOCK")) sort_block = (atoi(e) == 256) ? 256 : 512;
         if (const char* e = getenv("SA_HIP_INITIAL_CHARS")) initial_chars_override = atoi(e);
         if (const char* e = getenv("SA_HIP_CHUNK_ROUNDS")) chunk_rounds_before_doubling = atoi(e);
+        if (const char* e = getenv("SA_HIP_ADAPTIVE_DOUBLING")) adaptive_doubling = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_FUSE_HIST")) fuse_hist = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_FUSE_DIR")) fuse_directory = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_NARROW")) narrow_sort = atoi(e) != 0;
@@ -1239,9 +1241,16 @@ struct Builder {
             }
         }
 
+        u32 M_prev = 0;   // active-set size of the previous round (0: none yet)
         while (M && (L == 0 || h < L)) {
             const int gb = bits_for(G);
-            bool use_chunk = (L != 0) || (chunk_done < chunk_rounds_before_doubling);
+            // Chunk rounds read the next characters from the text; doubling rounds need the inverse suffix array
+            // (one random 4-byte write per suffix of the WHOLE text the first time) and pay off only on long
+            // repeats.  As long as the active set at least halves from round to round the remaining chunk rounds
+            // are cheaper than that scatter (words / names: 60.8M -> 20.5M -> 4.2M -> 0.5M -> 33K -> 633 -> 12), so
+            // doubling starts only when the set has stopped shrinking after the first chunk rounds.
+            const bool shrinking = M_prev != 0 && (u64)M * 2 <= (u64)M_prev;
+            bool use_chunk = (L != 0) || (chunk_done < chunk_rounds_before_doubling) || (adaptive_doubling && !have_isa && shrinking);
             int kc = 0;
             if (use_chunk) {
                 kc = (64 - gb) / b;
@@ -1302,6 +1311,7 @@ struct Builder {
             }
             stats.active_total += M;
             ++stats.rounds;
+            M_prev = M;
             h = h_next;
             const u32 M_next = tot[0];
             if (M_next && (L == 0 || h < L)) {

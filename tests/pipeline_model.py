@@ -67,12 +67,16 @@ def build_sa_model(text, max_suffix_length=0, chunk_rounds_before_doubling=2, k0
     apos = np.nonzero(act)[0]
     ahead = head[apos]
     chunk_done = 0
+    m_prev = 0
     while apos.size and (L == 0 or h < L):
         aidx = sa[apos].astype(np.int64)
         gid = (np.cumsum(ahead) - 1).astype(np.uint64)
         ngroups = int(gid[-1]) + 1
         gb = _bits_for(ngroups)
-        use_chunk = bool(L) or chunk_done < chunk_rounds_before_doubling
+        # doubling (inverse suffix array: one scatter over the whole text) only once the active set has stopped
+        # halving from round to round (sa_build.hpp, adaptive_doubling)
+        shrinking = m_prev != 0 and 2 * apos.size <= m_prev
+        use_chunk = bool(L) or chunk_done < chunk_rounds_before_doubling or (isa is None and shrinking)
         if use_chunk:
             kc = (64 - gb) // b
             if L:
@@ -111,6 +115,7 @@ def build_sa_model(text, max_suffix_length=0, chunk_rounds_before_doubling=2, k0
             gs = np.maximum.accumulate(np.where(nh, apos, 0))
             isa[sidx] = gs
         rounds.append((kind, h, h_next, int(apos.size), ngroups))
+        m_prev = int(apos.size)
         h = h_next
         keep = active_of(nh)
         apos = apos[keep]
