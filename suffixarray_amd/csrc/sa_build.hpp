@@ -857,7 +857,12 @@ struct Builder {
                 const double need = std::log(0.02 / (double)n) / std::log(c2);
                 int kk = (int)std::ceil(need);
                 if (kk < 1) kk = 1;
-                if (kk < kmax && pilot_dup_share <= 0.03) {
+                // the pilot's 8-byte windows repeat in an i.i.d. text too when the alphabet is small (4 symbols:
+                // 65 536 possible windows for 131 072 samples): compare with the share such a text would show
+                const double d_eff = 1.0 / std::pow(c2, 8.0);   // effective number of distinct windows
+                const double s_n = (double)PILOT_SAMPLES;
+                const double iid_share = 1.0 + d_eff * std::expm1(-s_n / d_eff) / s_n;
+                if (kk < kmax && pilot_dup_share <= iid_share + 0.03) {
                     const int passes = (kk * b + RADIX_BITS - 1) / RADIX_BITS;
                     kk = (passes * RADIX_BITS) / b;
                     k = kk < kmax ? kk : kmax;
