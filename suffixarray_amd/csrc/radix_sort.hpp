@@ -440,7 +440,7 @@ __device__ __forceinline__ void onesweep_tile(const SortPassArgs& a, const u32 t
 }
 
 template <int BLOCK, int ABL = 0, bool NARROW = false>
-__global__ __launch_bounds__(BLOCK, 4) void radix_onesweep_kernel(SortPassArgs a) {
+__global__ __launch_bounds__(BLOCK, (BLOCK == 256) ? 3 : 4) void radix_onesweep_kernel(SortPassArgs a) {   // 256: LDS allows 3 workgroups of 4 waves
     constexpr int WAVES = BLOCK / WAVE;
     constexpr int TILE = BLOCK * SORT_ITEMS;
     constexpr int WH = (WAVES * RADIX > NCHUNK * RADIX) ? WAVES * RADIX : NCHUNK * RADIX;
