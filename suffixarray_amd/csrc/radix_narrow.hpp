@@ -446,10 +446,9 @@ __device__ __forceinline__ void shl_or_inplace(u32& acc, u32 x, int s) {
     asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "s"(s));
 }
 
-// CB, CK0: b and k0 as compile-time constants (0: run-time values of the arguments).  Not instantiated: with b = 5,
-// k0 = 8 as constants the compiler merges a key's eight byte reads into one unaligned ds_read_b64 and the pass
-// gets slower (4.54 vs 3.69 ms at N = 1e9).
-template <bool FULL, int BLOCK, int CB, int CK0>
+// (b and k0 stay run-time values: with b = 5, k0 = 8 as compile-time constants the compiler merges a key's eight byte
+// reads into one unaligned ds_read_b64 and the pass gets slower, 4.54 vs 3.69 ms at N = 1e9.)
+template <bool FULL, int BLOCK>
 __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 tile, const u32 chunk,
                                               const u32 tile_n, u32* s_keys, u32* s_whist, u32* s_gdelta, u32* s_wsum,
                                               u8* s_code, const u8* s_map) {
@@ -490,27 +489,11 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
     u32 hi[ITEMS], lo[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) { hi[j] = 0; lo[j] = 0; }
-    // three loops with ONE body each (characters entirely in the upper word, at most one character that straddles
-    // bit 32, characters entirely in the lower word): a single loop with the three cases as branches made the
-    // compiler shuffle all 32 accumulators through copies on every iteration (64 moves for 16 useful operations);
-    // the accumulate is an in-place v_lshl_or_b32 (as C it is computed into a new register and copied back)
+    // three loops with one body each: characters entirely in the upper word, at most one character that straddles
+    // bit 32, characters entirely in the lower word (the shift amounts are scalar, the accumulate is one in-place
+    // v_lshl_or_b32 per character and key)
     const u8* cp = s_code + woff;
-    if constexpr (CB > 0 && CK0 > 0) {
-#pragma unroll
-        for (int c = 0; c < CK0; ++c) {
-            constexpr int b = CB;
-            const int sh = 64 - b * (c + 1);
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
-                const u32 code = cp[c + j * WAVE];
-                if (sh >= 32) hi[j] |= code << (sh - 32);
-                else {
-                    lo[j] |= code << sh;
-                    if (sh + b > 32) hi[j] |= code >> (32 - sh);
-                }
-            }
-        }
-    } else {
+    {
         int c = 0;
         for (; c < a.k0 && 64 - a.b * (c + 1) >= 32; ++c, ++cp) {
             const int s_hi = 32 - a.b * (c + 1);
@@ -623,7 +606,7 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
 }
 
 // 79 VGPRs and 50 KB of LDS: three workgroups (24 waves) per CU
-template <int BLOCK, int CB = 0, int CK0 = 0>
+template <int BLOCK>
 __global__ __launch_bounds__(BLOCK, 6) void text_top_pass_kernel(TextPassArgs a) {
     constexpr int WAVES = BLOCK / WAVE;
     constexpr u32 TILE = BLOCK * SORT_ITEMS;
@@ -659,9 +642,9 @@ __global__ __launch_bounds__(BLOCK, 6) void text_top_pass_kernel(TextPassArgs a)
     const u32 chunk = s_chunk;
     const u64 rest = a.n - (u64)tile * TILE;
     if (rest >= (u64)TILE)
-        text_top_tile<true, BLOCK, CB, CK0>(a, tile, chunk, TILE, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
+        text_top_tile<true, BLOCK>(a, tile, chunk, TILE, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
     else
-        text_top_tile<false, BLOCK, 0, 0>(a, tile, chunk, (u32)rest, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
+        text_top_tile<false, BLOCK>(a, tile, chunk, (u32)rest, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
 }
 
 // ---- host driver --------------------------------------------------------------------------------------
