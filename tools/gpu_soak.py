@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from suffixarray_amd import _capi, synth
 rng = np.random.default_rng(1)
-cases = [("d1_1e9", synth.d1_uniform27(1_000_000_000), 0, 25),
+D1_REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+cases = [("d1_1e9", synth.d1_uniform27(1_000_000_000), 0, D1_REPS),
          ("repeat_2^26", np.tile(rng.integers(97, 123, 1 << 20, dtype=np.uint8), 64), 0, 8),
          ("d2_2e8", synth.d2_words(200_000_000), 0, 8),
          ("d2_2e8_L32", None, 32, 8)]
