@@ -209,32 +209,55 @@ __global__ __launch_bounds__(BLD_BLOCK) void flags_kernel(const u64* __restrict_
     __shared__ u32 s_a[BLD_BLOCK / WAVE], s_h[BLD_BLOCK / WAVE];
     const u64 base = (u64)blockIdx.x * BLD_TILE;
     u32 ca = 0, ch = 0;
-#pragma unroll 4
-    for (int it = 0; it < BLD_ITEMS; ++it) {
-        const u64 j = base + (u64)it * BLD_BLOCK + threadIdx.x;
-        if (j < n) {
-            const u64 k = keys[j];
-            const u64 kprev = (j == 0) ? 0ull : keys[j - 1];
-            const bool head = (j == 0) || (kprev != k);
-            const bool next_head = (j + 1 == n) || (keys[j + 1] != k);
-            if (dirargs.dir && head) {
-                const int ds = 64 - dirargs.dbits;
-                const u32 bj = (u32)(k >> ds);
-                const u32 first = (j == 0) ? 0u : (u32)(kprev >> ds) + 1u;
-                if (first <= bj) dir_emit(dirargs, first, bj, (u32)j);
-            }
-            if (dirargs.dir && j + 1 == n)   // buckets above the last key, and the end marker dir[2^dbits]
-                dir_emit(dirargs, (u32)(k >> (64 - dirargs.dbits)) + 1u, 1u << dirargs.dbits, n);
-            const bool act = !(head && next_head);
-            lf[j] = (u8)((head ? 1 : 0) | (act ? 2 : 0));
-            ca += act;
-            ch += (act && head);
-            if (apos) {
-                const u32 slot = apos[j];
-                sa_out[slot] = sidx[j];
-                if (head) gflags[slot] = 1;
+    // four consecutive elements per thread and step: two 16-byte key loads + the two neighbouring keys instead of
+    // three 8-byte loads per element, and one 4-byte store of the four flag bytes instead of four 1-byte stores
+    // (the key and flag buffers are 16-byte aligned; the flag buffer carries >= 64 bytes of slack)
+    static_assert(BLD_ITEMS % 4 == 0, "four elements per step");
+#pragma unroll
+    for (int it = 0; it < BLD_ITEMS / 4; ++it) {
+        const u64 j0 = base + (u64)it * (BLD_BLOCK * 4) + (u64)threadIdx.x * 4;
+        if (j0 >= n) continue;
+        u64 k[6];   // keys j0-1 .. j0+4
+        if (j0 + 4 <= n) {
+            const uint4 x0 = *reinterpret_cast<const uint4*>(keys + j0);
+            const uint4 x1 = *reinterpret_cast<const uint4*>(keys + j0 + 2);
+            k[1] = ((u64)x0.y << 32) | x0.x; k[2] = ((u64)x0.w << 32) | x0.z;
+            k[3] = ((u64)x1.y << 32) | x1.x; k[4] = ((u64)x1.w << 32) | x1.z;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) k[1 + e] = (j0 + e < n) ? keys[j0 + e] : 0ull;
+        }
+        k[0] = (j0 > 0) ? keys[j0 - 1] : 0ull;
+        k[5] = (j0 + 4 < n) ? keys[j0 + 4] : 0ull;
+        u32 fl = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const u64 j = j0 + e;
+            if (j < n) {
+                const u64 kk = k[1 + e], kprev = k[e];
+                const bool head = (j == 0) || (kprev != kk);
+                const bool next_head = (j + 1 == n) || (k[2 + e] != kk);
+                if (dirargs.dir && head) {
+                    const int ds = 64 - dirargs.dbits;
+                    const u32 bj = (u32)(kk >> ds);
+                    const u32 first = (j == 0) ? 0u : (u32)(kprev >> ds) + 1u;
+                    if (first <= bj) dir_emit(dirargs, first, bj, (u32)j);
+                }
+                if (dirargs.dir && j + 1 == n)   // buckets above the last key, and the end marker dir[2^dbits]
+                    dir_emit(dirargs, (u32)(kk >> (64 - dirargs.dbits)) + 1u, 1u << dirargs.dbits, n);
+                const bool act = !(head && next_head);
+                fl |= (u32)((head ? 1 : 0) | (act ? 2 : 0)) << (8 * e);
+                ca += act;
+                ch += (act && head);
+                if (apos) {
+                    const u32 slot = apos[j];
+                    sa_out[slot] = sidx[j];
+                    if (head) gflags[slot] = 1;
+                }
             }
         }
+        if (j0 + 4 <= n) *reinterpret_cast<u32*>(lf + j0) = fl;
+        else for (int e = 0; e < 4 && j0 + e < n; ++e) lf[j0 + e] = (u8)(fl >> (8 * e));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
