@@ -164,6 +164,7 @@ __global__ __launch_bounds__(BLD_BLOCK) void keygen_kernel(const u8* __restrict_
 // runs of up to DIR_INLINE buckets are written here, longer ones (unused codes of the compacted
 // alphabet leave holes of up to 2^dbits / 8 buckets) are queued for dir_fill_kernel.
 constexpr u32 DIR_INLINE = 8;
+constexpr u32 DIR_PIECE = 1u << 14;
 struct DirArgs {
     u32* dir;        // [2^dbits + 1], or nullptr
     int dbits;
@@ -176,9 +177,14 @@ __device__ __forceinline__ void dir_emit(const DirArgs& d, u32 first, u32 last, 
     if (last - first < DIR_INLINE) {
         for (u32 bkt = first; bkt <= last; ++bkt) d.dir[bkt] = value;
     } else {
-        const u32 slot = atomicAdd(d.gap_count, 1u);
-        if (slot < d.gap_cap) d.gaps[slot] = make_uint4(first, last, value, 0u);
-        else __hip_atomic_store(&d.dstat->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // cannot happen: see gap_cap
+        // queued in pieces of at most DIR_PIECE buckets: dir_fill_kernel gives one piece to one workgroup, and the
+        // holes of a compacted alphabet reach 2^dbits / 8 buckets (one workgroup filling 2M entries took 0.2 ms)
+        for (u64 f = first; f <= (u64)last; f += DIR_PIECE) {
+            const u64 l = (f + DIR_PIECE - 1 < (u64)last) ? f + DIR_PIECE - 1 : (u64)last;
+            const u32 slot = atomicAdd(d.gap_count, 1u);
+            if (slot < d.gap_cap) d.gaps[slot] = make_uint4((u32)f, (u32)l, value, 0u);
+            else __hip_atomic_store(&d.dstat->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // cannot happen: see gap_cap
+        }
     }
 }
 
@@ -1085,7 +1091,8 @@ struct Builder {
     static int dir_coarse_bits(int d) { return d > 16 ? 14 : 0; }
     static size_t dir_gap_offset(u64 nb) { return (((size_t)nb + (1u << 14) + 1) * 4 + 15) & ~(size_t)15; }
     // a queued run holds more than DIR_INLINE buckets and runs are disjoint, so nb / DIR_INLINE entries suffice
-    static u32 dir_gap_cap(u64 nb) { return (u32)(nb / DIR_INLINE + 2); }
+    // (+ one more entry per DIR_PIECE buckets for the pieces of long runs)
+    static u32 dir_gap_cap(u64 nb) { return (u32)(nb / DIR_INLINE + nb / DIR_PIECE + 4); }
     int directory_layout(u64 count) {
         int lg = 0;
         while ((1ull << lg) < count) ++lg;
