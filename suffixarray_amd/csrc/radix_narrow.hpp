@@ -8,13 +8,14 @@
 // that keep every record inside its bucket (256 independent sorts run side by side):
 //
 //   pass            reads            writes           bytes / record
-//   top digit       u64 key          u32 low key, u32 value (iota)     8 + 8
+//   top digit       text (1 byte)    u32 low key, u32 value (iota)     1 + 8    (text_top_pass_kernel; from a u64 key
+//                                                                                array instead: 8 + 8, radix_onesweep_kernel<.., true>)
 //   histogram       u32 low key      -                                 4        (digit 0 per bucket)
 //   narrow passes   u32 key, u32 val u32 key, u32 val                  8 + 8
 //   last pass       u32 key, u32 val u64 key (rebuilt), u32 val        8 + 12
 //
-// 40-bit keys (the build's choice for near-random text: 8 characters of 5 bits): 16 + 4 + 3*16 + 20 = 88
-// bytes per record instead of 20 + 4*24 = 116.
+// 40-bit keys (the build's choice for near-random text: 8 characters of 5 bits): 1 (top-digit histogram) + 9 + 4 +
+// 3*16 + 20 = 82 bytes per character instead of 9 (key generation) + 20 + 4*24 = 125.
 //
 // Geometry of the narrow passes: bucket b = records [bstart[b], bstart[b+1]) of the arrays; its tiles
 // start at the bucket start (no tile straddles two buckets, the last tile of a bucket is partial).
