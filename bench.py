@@ -45,7 +45,7 @@ def usable_cpus():
 
 
 PASS_KERNELS = ["radix_onesweep_kernel<512, 0, false>", "radix_onesweep_kernel<512, 0, true>",
-                "seg_onesweep_kernel<512, 16, false, true>", "seg_onesweep_kernel<512, 16, true, true>"]   # sa_hip_build_stats.pass_*
+                "seg_onesweep_kernel<512, 24, false, true>", "seg_onesweep_kernel<512, 24, true, true>"]   # sa_hip_build_stats.pass_*
 
 
 def pmc_traffic(n, kernel):

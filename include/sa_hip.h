@@ -166,8 +166,8 @@ typedef struct sa_hip_build_stats {
     /* the sort passes by kernel: [0] radix_onesweep_kernel<512> (u64 key + u32 value in and out),
      * [1] top digit of a narrow sort (u32 key + u32 value out): radix_onesweep_kernel<512,0,true> from u64
      *     keys, or text_top_pass_kernel<512> from the text (text_top_pass),
-     * [2] seg_onesweep_kernel<512,16,false,true> (u32 key + u32 value in and out),
-     * [3] seg_onesweep_kernel<512,16,true,true> (u32 key + u32 value in, u64 key + u32 value out) */
+     * [2] seg_onesweep_kernel<512,24,false,true> (u32 key + u32 value in and out),
+     * [3] seg_onesweep_kernel<512,24,true,true> (u32 key + u32 value in, u64 key + u32 value out) */
     double   pass_ms[4];
     uint64_t pass_bytes[4];      /* algorithmic bytes (read + written)                      */
     uint32_t pass_launches[4];

@@ -32,6 +32,7 @@
 namespace sa {
 
 constexpr int NARROW_MAX_PASSES = 4;
+constexpr int SEG_ITEMS = 24;   // records per thread of the narrow passes: tiles of 512 x 24 = 12288 records
 
 struct SegPlan {              // device resident, written by seg_plan_kernel
     u32 bstart[RADIX + 1];    // first record of bucket b; [RADIX] = n
@@ -40,14 +41,14 @@ struct SegPlan {              // device resident, written by seg_plan_kernel
 };
 
 // bucket sizes from the per-chunk histogram of the top digit -> SegPlan (one workgroup of 256)
-__global__ __launch_bounds__(256) void seg_plan_kernel(const u32* __restrict__ hist_top, u32 tile_shift, SegPlan* __restrict__ plan) {
+__global__ __launch_bounds__(256) void seg_plan_kernel(const u32* __restrict__ hist_top, u32 tile, SegPlan* __restrict__ plan) {
     __shared__ u32 s_w[2][4];
     __shared__ u32 s_tp[RADIX + 1];
     const int d = threadIdx.x, lane = d & 63, w = d >> 6;
     u32 size = 0;
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) size += hist_top[c * RADIX + d];
-    const u32 tiles = (u32)(((u64)size + (1u << tile_shift) - 1) >> tile_shift);
+    const u32 tiles = (u32)(((u64)size + tile - 1) / tile);
     u32 is = size, it = tiles;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -90,10 +91,10 @@ __device__ __forceinline__ u32 seg_bucket_of(const u32* tprefix, u32 f) {
 // histogram of digit [shift, shift + 8) of the narrow keys, per bucket: hist[b][d]; the LDS histogram is kept in
 // SEG_HIST_COPIES lane-selected copies (fewer lanes of a wave on the same counter)
 constexpr int SEG_HIST_COPIES = 4;
-template <int BLOCK>
+template <int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void seg_hist_kernel(const u32* __restrict__ keys, const SegPlan* __restrict__ plan, int shift,
                                                          u32 mask, u32* __restrict__ hist, u32 tiles_per_block) {
-    constexpr u32 TILE = BLOCK * SORT_ITEMS;
+    constexpr u32 TILE = BLOCK * ITEMS;
     constexpr int CS = RADIX + 1;
     __shared__ u32 s_h[SEG_HIST_COPIES * CS];
     __shared__ u32 s_t[RADIX + 1];
@@ -123,11 +124,11 @@ __global__ __launch_bounds__(BLOCK) void seg_hist_kernel(const u32* __restrict__
         const u32 end = plan->bstart[b + 1];
         const u32 len = (end - start) < TILE ? (end - start) : TILE;
         if (len == TILE) {   // all loads of the tile in flight before the first LDS atomic
-            u32 k[SORT_ITEMS];
+            u32 k[ITEMS];
 #pragma unroll
-            for (int j = 0; j < SORT_ITEMS; ++j) k[j] = keys[start + j * BLOCK + threadIdx.x];
+            for (int j = 0; j < ITEMS; ++j) k[j] = keys[start + j * BLOCK + threadIdx.x];
 #pragma unroll
-            for (int j = 0; j < SORT_ITEMS; ++j) atomicAdd(&my[(k[j] >> shift) & mask], 1u);
+            for (int j = 0; j < ITEMS; ++j) atomicAdd(&my[(k[j] >> shift) & mask], 1u);
         } else {
             for (u32 l = threadIdx.x; l < len; l += BLOCK) atomicAdd(&my[(keys[start + l] >> shift) & mask], 1u);
         }
@@ -302,16 +303,17 @@ __device__ __forceinline__ void seg_tile(const SegPassArgs& a, const u32 flat, c
     }
 }
 
-// Occupancy is what this kernel lives on: with the values loaded right after the ranking it needs 104 VGPRs (two
-// workgroups = two tiles in flight per CU); loading them only before they are staged (LATEV) fits 80 VGPRs (3-5 spilled)
-// and, with 44 KB of LDS, THREE workgroups per CU: 3.80-3.86 -> 3.44-3.49 ms per pass at N = 1e9.  It is the number of
-// tiles in flight that counts, not the number of waves: 1024 x 8 threads x records (64 VGPRs, two workgroups of 16 waves)
-// ran at the speed of 512 x 16 with two workgroups (3.76 vs 3.78 ms).
+// Bytes in flight per CU are what this kernel lives on.  512 x 16 records with the values loaded right after the
+// ranking: 104 VGPRs, two workgroups per CU (2 x 128 KB in flight), 3.80-3.86 ms per pass at N = 1e9.  Values loaded only
+// before they are staged (LATEV): 80 VGPRs, 44 KB of LDS, THREE workgroups (3 x 128 KB): 3.44-3.49 ms.  512 x 24 records
+// (tiles of 12288, 127 VGPRs, 60 KB of LDS, two workgroups = 2 x 192 KB, digit runs of 48 instead of 32 records and a
+// third fewer look-backs): 3.29-3.31 ms against 3.56 ms on the same box -- the instantiated form.  512 x 32 spills
+// (63 registers); it is not the number of waves that counts: 1024 x 8 threads x records (64 VGPRs, two workgroups of
+// 16 waves) ran at the speed of 512 x 16 with two workgroups (3.76 vs 3.78 ms).
 template <int BLOCK, int ITEMS, bool LAST, bool LATEV = true>
-__global__ __launch_bounds__(BLOCK, LATEV ? 6 : 4) void seg_onesweep_kernel(SegPassArgs a) {
+__global__ __launch_bounds__(BLOCK, (ITEMS > 16) ? 4 : (LATEV ? 6 : 4)) void seg_onesweep_kernel(SegPassArgs a) {
     constexpr int WAVES = BLOCK / WAVE;
     constexpr u32 TILE = BLOCK * ITEMS;
-    static_assert(TILE == 512 * SORT_ITEMS, "the plan's tile size");
     __shared__ __attribute__((aligned(16))) u32 s_keys[TILE];   // reused for the values
     __shared__ u32 s_whist[WAVES * RADIX];
     __shared__ u32 s_gdelta[RADIX];
@@ -755,13 +757,14 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
             ws.pass_records += n; ws.pass_bytes += (u64)n * 16u; ws.passes += 1;
         }
     }
-    hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(256), 0, stream, ws.hist(0), g.tile_shift, nw.plan);
-    const u32 flat_max = g.tiles + RADIX;   // >= sum over buckets of ceil(size / tile)
+    const u32 seg_tile_n = 512u * SEG_ITEMS;
+    hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(256), 0, stream, ws.hist(0), seg_tile_n, nw.plan);
+    const u32 flat_max = n / seg_tile_n + 1 + RADIX;   // >= sum over buckets of ceil(size / tile)
     // narrow keys now in keysB (u32), values in valsB; histogram of the first narrow digit per bucket
     {
         const u32 tpb = 4;
         const u32 mask0 = (1u << ((np == 1) ? lo_bits : RADIX_BITS)) - 1u;
-        hipLaunchKernelGGL((seg_hist_kernel<512>), dim3(div_up(flat_max, tpb)), dim3(512), 0, stream,
+        hipLaunchKernelGGL((seg_hist_kernel<512, SEG_ITEMS>), dim3(div_up(flat_max, tpb)), dim3(512), 0, stream,
                            reinterpret_cast<const u32*>(keysB), nw.plan, 0, mask0, nw.hist, tpb);
     }
     u32* kin = reinterpret_cast<u32*>(keysB); u32* vin = valsB;
@@ -787,8 +790,8 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
         a.status = ws.status; a.ticket = nw.tickets + p * NCHUNK; a.epoch = ws.epoch; a.dstat = ws.dstat;
         a.lo_shift = begin_bit; a.incl_mask = SA_INCL_MASK;   // every 4th tile: 1 / 3 / 7 / 15 measured 3.84 / 3.74 / 3.80 / 3.98 ms per pass
         if ((rc = ws.timer.start(stream, last ? 3 : 2))) return rc;
-        if (last) hipLaunchKernelGGL((seg_onesweep_kernel<512, 16, true>), dim3(flat_max), dim3(512), 0, stream, a);
-        else hipLaunchKernelGGL((seg_onesweep_kernel<512, 16, false>), dim3(flat_max), dim3(512), 0, stream, a);
+        if (last) hipLaunchKernelGGL((seg_onesweep_kernel<512, SEG_ITEMS, true>), dim3(flat_max), dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((seg_onesweep_kernel<512, SEG_ITEMS, false>), dim3(flat_max), dim3(512), 0, stream, a);
         if ((rc = ws.timer.stop(stream, (u64)n * (last ? 20u : 16u)))) return rc;
         ws.pass_records += n; ws.pass_bytes += (u64)n * (last ? 20u : 16u); ws.passes += 1;
         u32* tk = kin; kin = kout; kout = tk;

@@ -9,7 +9,7 @@ WRITE_SIZE is exact."""
 import csv, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = sys.argv[4] if len(sys.argv) > 4 else "seg_onesweep_kernel<512, 16, false, true>"   # substring of the rocprofv3 kernel name
+KERNEL = sys.argv[4] if len(sys.argv) > 4 else "seg_onesweep_kernel<512, 24, false, true>"   # substring of the rocprofv3 kernel name
 
 
 def rows(path, counter):
@@ -41,7 +41,7 @@ def main():
         "fetch_bytes_total": sum(fb),
         "write_bytes_total": sum(wb),
         "traffic_bytes_per_launch": (sum(fb) + sum(wb)) / n,
-        "algorithmic_bytes_per_launch": 16000000000.0 if "seg_onesweep_kernel<512, 16, false, true>" in KERNEL else None,
+        "algorithmic_bytes_per_launch": 16000000000.0 if "seg_onesweep_kernel<512, 24, false, true>" in KERNEL else None,
         "corrections": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request; calibrated with 8-byte and 4-byte-per-lane copy "
                        "kernels in tools/sortbench.hip), WRITE_SIZE exact, counters in KiB",
         "commands": [
