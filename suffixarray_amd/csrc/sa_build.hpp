@@ -543,8 +543,9 @@ __global__ __launch_bounds__(256) void tiny_groups_kernel(const u8* __restrict__
         SA_CE(2, 4) SA_CE(3, 5)
         SA_CE(3, 4)
 #undef SA_CE
-        // a network does not compare every adjacent pair of its output: make sure the order is strict
-        if (!truncated) {
+        // a network does not compare every adjacent pair of its output: make sure the order is strict (a pair has
+        // been compared by SA_CE(0, 1) already: equal -> unresolved)
+        if (!truncated && size > 2) {
 #pragma unroll
             for (int k = 0; k + 1 < TINY_MAX; ++k)
                 if (k + 1 < size && !unresolved && cmp_suffix_pair(text, n, v[k], v[k + 1], h, limit) >= 0) unresolved = true;
