@@ -103,7 +103,9 @@ class SuffixArray:
             take = min(slab, end - pos)
             hits = self._index.sa_range(pos, take).astype(np.int64)
             ids = np.searchsorted(self._row_starts, hits, side="right") - 1
-            for r in ids.tolist():
+            # distinct rows in order of first appearance (vectorised; the Python set only spans slabs)
+            _, first_at = np.unique(ids, return_index=True)
+            for r in ids[np.sort(first_at)].tolist():
                 if r not in seen:
                     seen.add(r)
                     rows.append(r)
@@ -115,15 +117,28 @@ class SuffixArray:
     def _materialise(self, rows):
         if self._mode == "documents":
             return [self._documents[r] for r in rows.tolist()]
+        # the file is mapped once (the reference re-opens it and does one fseek + fread per row,
+        # engine.c:1334-1390); a row without a quote character is split directly, the rest goes through the csv module
+        mm = self._csv_map()
+        off = self._row_file_offsets
+        cols = self.columns
         out = []
-        with open(self.csv_filename, "rb") as f:
-            for r in rows.tolist():
-                f.seek(int(self._row_file_offsets[r]))
-                n = int(self._row_file_offsets[r + 1] - self._row_file_offsets[r])
-                line = f.read(n).decode("utf-8", "replace")
-                rec = next(_csv.reader(io.StringIO(line)))
-                out.append(dict(zip(self.columns, rec)))
+        for r in rows.tolist():
+            raw = mm[int(off[r]):int(off[r + 1])]
+            if b'"' in raw:
+                rec = next(_csv.reader(io.StringIO(raw.decode("utf-8", "replace"))))
+            else:
+                rec = raw.decode("utf-8", "replace").rstrip("\r\n").split(",")
+            out.append(dict(zip(cols, rec)))
         return out
+
+    def _csv_map(self):
+        mm = getattr(self, "_csv_mm", None)
+        if mm is None:
+            import mmap
+            self._csv_fh = open(self.csv_filename, "rb")
+            mm = self._csv_mm = mmap.mmap(self._csv_fh.fileno(), 0, access=mmap.ACCESS_READ)
+        return mm
 
     def query_records(self, substring: str, k: int = 1000):
         """pyx:209-267: records containing `substring` (case-insensitive ASCII), at most k."""
@@ -204,3 +219,8 @@ class SuffixArray:
         if self._index is not None:
             self._index.close()
             self._index = None
+        mm = getattr(self, "_csv_mm", None)
+        if mm is not None:
+            mm.close()
+            self._csv_fh.close()
+            self._csv_mm = None

@@ -54,6 +54,8 @@ cdef class SuffixArray:
     cdef list _documents
     cdef object _row_starts
     cdef object _row_file_offsets
+    cdef object _csv_mm
+    cdef object _csv_fh
     cdef public list columns
     cdef public str csv_filename
 
@@ -85,6 +87,10 @@ cdef class SuffixArray:
         if self._idx != NULL:
             sa_hip_index_destroy(self._idx)
             self._idx = NULL
+        if self._csv_mm is not None:
+            self._csv_mm.close()
+            self._csv_fh.close()
+            self._csv_mm = None
 
     cdef _set_text(self, bytes text):
         cdef uint64_t n = len(text)
@@ -169,7 +175,8 @@ cdef class SuffixArray:
                 rc = sa_hip_index_get_sa_range(self._idx, pos, take, &hv[0])
             _check(rc)
             ids = np.searchsorted(self._row_starts, hits[:take].astype(np.int64), side="right") - 1
-            for r in ids.tolist():
+            _, first_at = np.unique(ids, return_index=True)   # distinct rows in order of first appearance
+            for r in ids[np.sort(first_at)].tolist():
                 if r not in seen:
                     seen.add(r)
                     rows.append(r)
@@ -181,13 +188,22 @@ cdef class SuffixArray:
     cdef _materialise(self, list rows):
         if self._mode == "documents":
             return [self._documents[r] for r in rows]
+        # the file is mapped once (the reference re-opens it and does one fseek + fread per row,
+        # engine.c:1334-1390); a row without a quote character is split directly
+        if self._csv_mm is None:
+            import mmap
+            self._csv_fh = open(self.csv_filename, "rb")
+            self._csv_mm = mmap.mmap(self._csv_fh.fileno(), 0, access=mmap.ACCESS_READ)
+        mm = self._csv_mm
+        off = self._row_file_offsets
         out = []
-        with open(self.csv_filename, "rb") as f:
-            for r in rows:
-                f.seek(int(self._row_file_offsets[r]))
-                line = f.read(int(self._row_file_offsets[r + 1] - self._row_file_offsets[r])).decode("utf-8", "replace")
-                rec = next(_csv.reader(_io.StringIO(line)))
-                out.append(dict(zip(self.columns, rec)))
+        for r in rows:
+            raw = mm[int(off[r]):int(off[r + 1])]
+            if b'"' in raw:
+                rec = next(_csv.reader(_io.StringIO(raw.decode("utf-8", "replace"))))
+            else:
+                rec = raw.decode("utf-8", "replace").rstrip("\r\n").split(",")
+            out.append(dict(zip(self.columns, rec)))
         return out
 
     def query_records(self, substring: str, k: int = 1000):
