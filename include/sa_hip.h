@@ -135,6 +135,12 @@ int sa_hip_query_batch_device(sa_hip_index* idx, const void* patterns_dev, const
                               uint64_t Q, void* out_dev);
 /* Copy up to `cap` suffix positions SA[first .. first+count) to the host (hit materialisation). */
 int sa_hip_index_get_sa_range(sa_hip_index* idx, uint64_t first, uint64_t count, uint32_t* out_host);
+/* ONE query with its first hits, the latency path of record retrieval (get_matching_records, engine.c:1167-1215,
+ * called per query by pyx:209-267): *range as in sa_hip_query_batch, hits[0 .. *nhits) = SA[first .. first + *nhits),
+ * *nhits = min(number of hits, max_hits, 4096).  Pattern, range and hits travel through one pinned host block that
+ * the kernels read and write directly: two small launches and one synchronisation, no copy calls. */
+int sa_hip_index_query_hits(sa_hip_index* idx, const uint8_t* pattern, uint64_t len, uint32_t max_hits,
+                            sa_hip_pair_u32* range, uint32_t* hits, uint32_t* nhits);
 
 int sa_hip_index_sync(sa_hip_index* idx);
 

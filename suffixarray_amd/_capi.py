@@ -24,7 +24,7 @@ EXPORTS = [
     "sa_hip_index_max_suffix_length", "sa_hip_index_text_dev", "sa_hip_index_sa_dev",
     "sa_hip_index_stream", "sa_hip_index_get_sa_u32", "sa_hip_index_get_sa_i64",
     "sa_hip_index_get_freq", "sa_hip_query_batch", "sa_hip_query_batch_device",
-    "sa_hip_index_get_sa_range", "sa_hip_index_sync", "sa_hip_index_verify", "sa_hip_index_build_stats",
+    "sa_hip_index_get_sa_range", "sa_hip_index_query_hits", "sa_hip_index_sync", "sa_hip_index_verify", "sa_hip_index_build_stats",
     "sa_hip_index_query_stats", "sa_hip_csv_extract_column", "sa_hip_csv_free", "sa_hip_synth_csv", "sa_hip_sort_pairs", "sa_hip_synth_uniform27", "sa_hip_last_error", "sa_hip_version",
 ]
 
@@ -131,6 +131,8 @@ def lib():
     L.sa_hip_query_batch_device.argtypes = [vp, vp, vp, u64, vp]
     L.sa_hip_index_get_sa_range.restype = C.c_int
     L.sa_hip_index_get_sa_range.argtypes = [vp, u64, u64, vp]
+    L.sa_hip_index_query_hits.restype = C.c_int
+    L.sa_hip_index_query_hits.argtypes = [vp, C.c_char_p, u64, C.c_uint32, C.POINTER(PairU32), vp, C.POINTER(C.c_uint32)]
     L.sa_hip_index_sync.restype = C.c_int
     L.sa_hip_index_sync.argtypes = [vp]
     L.sa_hip_index_verify.restype = C.c_int
@@ -255,6 +257,15 @@ class DeviceIndex:
         out = np.empty(max(count, 1), dtype=np.uint32)
         check(self._lib.sa_hip_index_get_sa_range(self._h, first, count, out.ctypes.data))
         return out[:count]
+
+    def query_hits(self, pattern: bytes, max_hits: int = 4096):
+        """One query and its first hits in one call: ((first, second), SA[first .. first + nhits))."""
+        rng = PairU32()
+        hits = np.empty(max(min(max_hits, 4096), 1), dtype=np.uint32)
+        nh = C.c_uint32(0)
+        check(self._lib.sa_hip_index_query_hits(self._h, pattern, len(pattern), min(max_hits, 4096), C.byref(rng),
+                                                hits.ctypes.data, C.byref(nh)))
+        return (rng.first, rng.second), hits[:nh.value]
 
     def freq(self):
         out = np.zeros(256, dtype=np.uint64)

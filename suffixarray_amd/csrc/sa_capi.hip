@@ -22,6 +22,8 @@ struct sa_hip_index {
     // query staging (host-pointer API)
     DevBuf q_pat, q_off, q_out;
     DevBuf widen;
+    u8* qh_host = nullptr;   // pinned, device-mapped block of sa_hip_index_query_hits (QH_BYTES)
+    u8* qh_dev = nullptr;    // the same block as the device sees it
     hipEvent_t q_begin = nullptr, q_end = nullptr;
     sa_hip_query_stats qstats{};
 };
@@ -57,6 +59,22 @@ int launch_query(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q
     idx->qstats.q = Q;
     idx->qstats.kernel_ms = -1.0;  // resolved lazily by sa_hip_index_query_stats
     return 0;
+}
+
+// pinned block of sa_hip_index_query_hits: [0,8) range, [8,12) nhits, [64, 64 + 4*QH_MAX_HITS) hits,
+// [QH_OFF_OFFSETS, +16) offsets {0, len}, [QH_OFF_PATTERN, QH_BYTES - 64) pattern (zero padded)
+constexpr u32 QH_MAX_HITS = 4096;
+constexpr size_t QH_OFF_HITS = 64, QH_OFF_OFFSETS = QH_OFF_HITS + 4 * QH_MAX_HITS, QH_OFF_PATTERN = QH_OFF_OFFSETS + 64;
+constexpr size_t QH_BYTES = 64 * 1024;
+
+__global__ __launch_bounds__(256) void hits_copy_kernel(const u32* __restrict__ sa, const sa_hip_pair_u32* __restrict__ range,
+                                                        u32 max_hits, u32* __restrict__ hits, u32* __restrict__ nhits) {
+    const u32 first = range->first, second = range->second;
+    u32 count = 0;
+    if (first != 0xFFFFFFFFu && ((second - first + 1u) != 0u)) count = second - first + 1u;   // miss: second = first - 1
+    if (count > max_hits) count = max_hits;
+    for (u32 i = threadIdx.x; i < count; i += blockDim.x) hits[i] = sa[(u64)first + i];
+    if (threadIdx.x == 0) *nhits = count;
 }
 
 // one-shot helper for the libsais-/engine-compatible wrappers
@@ -109,6 +127,7 @@ void sa_hip_index_destroy(sa_hip_index* idx) {
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     idx->b.destroy();
     idx->q_pat.release(); idx->q_off.release(); idx->q_out.release(); idx->widen.release();
+    if (idx->qh_host) (void)hipHostFree(idx->qh_host);
     if (idx->q_begin) (void)hipEventDestroy(idx->q_begin);
     if (idx->q_end) (void)hipEventDestroy(idx->q_end);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -267,6 +286,38 @@ int sa_hip_query_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_
     if ((rc = launch_query(idx, idx->q_pat.as<u8>(), idx->q_off.as<u64>(), Q, idx->q_out.as<sa_hip_pair_u32>()))) return rc;
     SA_HIP_CHECK(hipMemcpyAsync(out, idx->q_out.p, (size_t)Q * sizeof(sa_hip_pair_u32), hipMemcpyDeviceToHost, idx->stream));
     SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+    return 0;
+}
+
+int sa_hip_index_query_hits(sa_hip_index* idx, const uint8_t* pattern, uint64_t len, uint32_t max_hits,
+                            sa_hip_pair_u32* range, uint32_t* hits, uint32_t* nhits) {
+    if (!idx || !idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_query_hits: no index");
+    if (!range || !nhits || (!pattern && len) || (!hits && max_hits)) return fail(SA_HIP_EINVAL, "sa_hip_index_query_hits: NULL argument");
+    if (len > QH_BYTES - 64 - QH_OFF_PATTERN) return fail(SA_HIP_EINVAL, "sa_hip_index_query_hits: pattern longer than 47 KB");
+    if (max_hits > QH_MAX_HITS) max_hits = QH_MAX_HITS;
+    std::lock_guard<std::mutex> g(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    if (!idx->qh_host) {
+        SA_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&idx->qh_host), QH_BYTES, hipHostMallocMapped));
+        SA_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&idx->qh_dev), idx->qh_host, 0));
+    }
+    u8* h = idx->qh_host;
+    u8* d = idx->qh_dev;
+    const u64 off[2] = {0, len};
+    memcpy(h + QH_OFF_OFFSETS, off, sizeof off);
+    if (len) memcpy(h + QH_OFF_PATTERN, pattern, len);
+    memset(h + QH_OFF_PATTERN + len, 0, 64);
+    if ((rc = launch_query(idx, d + QH_OFF_PATTERN, reinterpret_cast<const u64*>(d + QH_OFF_OFFSETS), 1,
+                           reinterpret_cast<sa_hip_pair_u32*>(d)))) return rc;
+    hipLaunchKernelGGL(hits_copy_kernel, dim3(1), dim3(256), 0, idx->stream, (const u32*)idx->b.sa,
+                       reinterpret_cast<const sa_hip_pair_u32*>(d), max_hits, reinterpret_cast<u32*>(d + QH_OFF_HITS),
+                       reinterpret_cast<u32*>(d + 8));
+    SA_HIP_CHECK(hipGetLastError());
+    SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+    memcpy(range, h, sizeof *range);
+    memcpy(nhits, h + 8, 4);
+    if (*nhits) memcpy(hits, h + QH_OFF_HITS, (size_t)*nhits * 4);
     return 0;
 }
 

@@ -89,19 +89,24 @@ class SuffixArray:
         pats = [_ascii_lower(s.encode("utf-8")) if isinstance(s, str) else _ascii_lower(bytes(s)) for s in substrings]
         return self._index.query_batch(pats)
 
-    def _rows_for_range(self, first, second, k):
+    def _rows_for_range(self, first, second, k, first_hits=None):
         if first == _capi.UINT32_MAX or ((second - first + 1) & 0xFFFFFFFF) == 0:
             return np.zeros(0, np.int64)
         count = int(second) - int(first) + 1
         rows = []
         seen = set()
         # hits arrive in SA order; walk them in slabs until k distinct rows are found
+        # (first_hits: SA[first .. first + len) already fetched by query_hits)
         pos = int(first)
         end = int(first) + count
         slab = max(4 * k, 1024)
         while pos < end and len(rows) < k:
             take = min(slab, end - pos)
-            hits = self._index.sa_range(pos, take).astype(np.int64)
+            if first_hits is not None and pos == int(first) and len(first_hits):
+                take = min(take, len(first_hits))
+                hits = first_hits[:take].astype(np.int64)
+            else:
+                hits = self._index.sa_range(pos, take).astype(np.int64)
             ids = np.searchsorted(self._row_starts, hits, side="right") - 1
             # distinct rows in order of first appearance (vectorised; the Python set only spans slabs)
             _, first_at = np.unique(ids, return_index=True)
@@ -144,7 +149,12 @@ class SuffixArray:
         """pyx:209-267: records containing `substring` (case-insensitive ASCII), at most k."""
         if substring == "":
             return []
-        return self.query_records_batch([substring], k)[0]
+        if self._index is None:
+            raise RuntimeError("index not built")
+        # one call fetches the range and the first hits (sa_hip_index_query_hits: no copy calls, one synchronisation)
+        pat = _ascii_lower(substring.encode("utf-8")) if isinstance(substring, str) else _ascii_lower(bytes(substring))
+        (first, second), hits = self._index.query_hits(pat, min(max(4 * k, 1024), 4096))
+        return self._materialise(self._rows_for_range(int(first), int(second), k, hits))
 
     def query_records_batch(self, substrings, k: int = 1000):
         if self._index is None:

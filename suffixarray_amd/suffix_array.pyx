@@ -29,6 +29,8 @@ cdef extern from "sa_hip.h":
     int sa_hip_query_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_t* offsets, uint64_t Q,
                            sa_hip_pair_u32* out) nogil
     int sa_hip_index_get_sa_range(sa_hip_index* idx, uint64_t first, uint64_t count, uint32_t* out_host) nogil
+    int sa_hip_index_query_hits(sa_hip_index* idx, const uint8_t* pattern, uint64_t len, uint32_t max_hits,
+                                sa_hip_pair_u32* range, uint32_t* hits, uint32_t* nhits) nogil
     uint64_t sa_hip_index_n(const sa_hip_index* idx) nogil
     const char* sa_hip_last_error()
 
@@ -156,7 +158,8 @@ cdef class SuffixArray:
         _check(rc)
         return out[:Q]
 
-    cdef _rows_for_range(self, uint32_t first, uint32_t second, int k):
+    cdef _rows_for_range(self, uint32_t first, uint32_t second, int k, first_hits=None):
+        # first_hits: SA[first .. first + len) already fetched by sa_hip_index_query_hits
         if first == 0xFFFFFFFF or ((second - first + 1) & 0xFFFFFFFF) == 0:
             return []
         cdef uint64_t pos = first
@@ -171,9 +174,13 @@ cdef class SuffixArray:
         hv = hits
         while pos < end and len(rows) < k:
             take = min(slab, end - pos)
-            with nogil:
-                rc = sa_hip_index_get_sa_range(self._idx, pos, take, &hv[0])
-            _check(rc)
+            if first_hits is not None and pos == first and len(first_hits):
+                take = min(take, <uint64_t>len(first_hits))
+                hits[:take] = first_hits[:take]
+            else:
+                with nogil:
+                    rc = sa_hip_index_get_sa_range(self._idx, pos, take, &hv[0])
+                _check(rc)
             ids = np.searchsorted(self._row_starts, hits[:take].astype(np.int64), side="right") - 1
             _, first_at = np.unique(ids, return_index=True)   # distinct rows in order of first appearance
             for r in ids[np.sort(first_at)].tolist():
@@ -210,7 +217,20 @@ cdef class SuffixArray:
         """pyx:209-267: records containing `substring` (case-insensitive ASCII), at most k."""
         if substring == "":
             return []
-        return self.query_records_batch([substring], k)[0]
+        # one call fetches the range and the first hits (no copy calls, one synchronisation)
+        cdef bytes pat = ascii_lower(substring.encode("utf-8"))
+        cdef const uint8_t* pp = <const uint8_t*>(<const char*>pat)
+        cdef uint64_t plen = len(pat)
+        cdef uint32_t cap = min(max(4 * k, 1024), 4096)
+        cdef uint32_t nh = 0
+        cdef sa_hip_pair_u32 rng
+        cdef int rc
+        fh = np.empty(cap, dtype=np.uint32)
+        cdef uint32_t[::1] fv = fh
+        with nogil:
+            rc = sa_hip_index_query_hits(self._idx, pp, plen, cap, &rng, &fv[0], &nh)
+        _check(rc)
+        return self._materialise(self._rows_for_range(rng.first, rng.second, k, fh[:nh]))
 
     def query_records_batch(self, substrings, k: int = 1000):
         live = [i for i, s in enumerate(substrings) if s != ""]

@@ -231,3 +231,23 @@ def test_directory_from_flags_pass_matches_searched_directory(gpu, oracle, monke
         if t.size <= 300_000:
             sa = oracle.sais(t).astype(np.uint32)
             assert np.array_equal(got["1"], oracle.query_batch(t, sa, 0xFFFFFFFF, pats)), name
+
+
+def test_query_hits_equals_batch_plus_range(gpu, oracle):
+    """sa_hip_index_query_hits (one query + its first hits through a pinned block) against the batched query and
+    sa_hip_index_get_sa_range, hits and misses, the all-smaller sentinel, an empty pattern, hit counts beyond the cap."""
+    rng = np.random.default_rng(5)
+    t = rng.integers(97, 101, 200_000).astype(np.uint8)   # 4 symbols: short patterns have many thousand hits
+    pats = cases.query_patterns(t, 200, rng, maxlen=12) + [b"a", b"ab", b"zzz", b"", bytes([96])]
+    with gpu.DeviceIndex(t.size, 0) as idx:
+        idx.build(t)
+        exp = idx.query_batch(pats)
+        for p, (f, s) in zip(pats, exp):
+            for cap in (1, 100, 4096, 10_000):
+                (f2, s2), hits = idx.query_hits(p, cap)
+                assert (f2, s2) == (int(f), int(s)), p
+                count = 0 if (f == 0xFFFFFFFF or ((int(s) - int(f) + 1) & 0xFFFFFFFF) == 0) else int(s) - int(f) + 1
+                take = min(count, cap, 4096)
+                assert hits.size == take, (p, cap)
+                if take:
+                    assert np.array_equal(hits, idx.sa_range(int(f), take))
