@@ -357,9 +357,11 @@ def csv_extract_column(path, column):
     check(lib().sa_hip_csv_extract_column(os.fsencode(path), column.encode("utf-8"), C.byref(col)))
     try:
         text = C.string_at(col.text, col.text_len) if col.text_len else b""
-        starts = np.frombuffer(C.string_at(col.row_text_starts, col.num_rows * 8), dtype=np.uint64).astype(np.int64) \
+        # one copy each out of the malloc'ed arrays (they are freed below); offsets are < 2^63: viewed as int64
+        i64p = C.POINTER(C.c_int64)
+        starts = np.ctypeslib.as_array(C.cast(col.row_text_starts, i64p), shape=(col.num_rows,)).copy() \
             if col.num_rows else np.zeros(0, np.int64)
-        offs = np.frombuffer(C.string_at(col.row_file_offsets, (col.num_rows + 1) * 8), dtype=np.uint64).astype(np.int64)
+        offs = np.ctypeslib.as_array(C.cast(col.row_file_offsets, i64p), shape=(col.num_rows + 1,)).copy()
         names, p = [], col.column_names
         for _ in range(col.num_columns):
             s = C.string_at(p)

@@ -86,9 +86,27 @@ struct CsvPart {
 };
 
 // Fast path of csv_parse_record for one wanted field: the field's bytes go straight into `text`
-// (lower-cased, embedded newlines as spaces).  Same state machine, same return values.
+// (lower-cased, embedded newlines as spaces).  Same state machine, same return values, but it moves in RUNS: outside
+// quotes up to the next of , " \n \r (table look-up), inside quotes up to the next " (memchr); a run of the wanted
+// field is appended with one resize and a branch-free lower-casing loop.
+struct CsvSpecial {
+    u8 t[256];
+    constexpr CsvSpecial() : t() { t[(u8)','] = 1; t[(u8)'"'] = 1; t[(u8)'\n'] = 1; t[(u8)'\r'] = 1; }
+};
+inline void csv_append_lower(std::vector<u8>& text, const u8* src, u64 len, bool newline_to_space) {
+    const size_t o = text.size();
+    text.resize(o + len);
+    u8* dst = text.data() + o;
+    for (u64 k = 0; k < len; ++k) {
+        const u8 c = src[k];
+        dst[k] = (u8)(c + (((u8)(c - 65u) < 26u) ? 32u : 0u));
+    }
+    if (newline_to_space)
+        for (u64 k = 0; k < len; ++k) if (dst[k] == '\n') dst[k] = ' ';
+}
 inline u32 csv_parse_record_into(CsvRecordCursor& cur, u32 want, std::vector<u8>& text, u64* row_start, u64* row_end,
                                  bool* first_field_empty) {
+    static constexpr CsvSpecial special{};
     const u8* d = cur.d;
     const u64 n = cur.n;
     u64 i = cur.i;
@@ -97,33 +115,39 @@ inline u32 csv_parse_record_into(CsvRecordCursor& cur, u32 want, std::vector<u8>
     bool in_quotes = false, f0_empty = true;
     while (true) {
         if (i >= n) { ++fidx; break; }
-        const u8 c = d[i];
         if (in_quotes) {
-            if (c == '"') {
-                if (i + 1 < n && d[i + 1] == '"') {
-                    if (fidx == want) text.push_back('"');
-                    if (fidx == 0) f0_empty = false;
-                    i += 2;
-                    continue;
-                }
-                in_quotes = false; ++i; continue;
+            const u8* q = static_cast<const u8*>(memchr(d + i, '"', n - i));
+            const u64 j = q ? (u64)(q - d) : n;
+            if (j > i) {
+                if (fidx == want) csv_append_lower(text, d + i, j - i, true);
+                if (fidx == 0) f0_empty = false;
+                i = j;
             }
-            if (fidx == want) text.push_back(c == '\n' ? (u8)' ' : (u8)((c >= 65 && c <= 90) ? c + 32 : c));
-            if (fidx == 0) f0_empty = false;
-            ++i;
-            continue;
+            if (i >= n) continue;   // unterminated quote: the record ends with the file
+            if (i + 1 < n && d[i + 1] == '"') {   // doubled quote = one literal quote
+                if (fidx == want) text.push_back('"');
+                if (fidx == 0) f0_empty = false;
+                i += 2;
+                continue;
+            }
+            in_quotes = false; ++i; continue;
         }
+        u64 j = i;
+        while (j < n && !special.t[d[j]]) ++j;
+        if (j > i) {
+            if (fidx == want) csv_append_lower(text, d + i, j - i, false);
+            if (fidx == 0) f0_empty = false;
+            i = j;
+            if (i >= n) continue;
+        }
+        const u8 c = d[i];
         if (c == '"') { in_quotes = true; ++i; }
         else if (c == ',') { ++fidx; ++i; }
-        else if (c == '\n' || c == '\r') {
+        else {   // '\n' or '\r'
             ++fidx;
             if (c == '\r' && i + 1 < n && d[i + 1] == '\n') ++i;
             ++i;
             break;
-        } else {
-            if (fidx == want) text.push_back((u8)((c >= 65 && c <= 90) ? c + 32 : c));
-            if (fidx == 0) f0_empty = false;
-            ++i;
         }
     }
     cur.i = i;
@@ -247,15 +271,24 @@ inline int csv_extract_column(const char* path, const char* column, sa_hip_csv_c
         memset(out, 0, sizeof *out);
         return fail(SA_HIP_ENOMEM, "sa_hip_csv_extract_column: out of host memory");
     }
-    u64 toff = 0, roff = 0;
-    for (auto& p : part) {
-        if (!p.text.empty()) memcpy(out->text + toff, p.text.data(), p.text.size());
-        for (size_t r = 0; r < p.starts.size(); ++r) {
-            out->row_text_starts[roff + r] = toff + p.starts[r];
-            out->row_file_offsets[roff + r] = p.offs[r];
-        }
-        toff += p.text.size();
-        roff += p.starts.size();
+    // every worker copies its own part into place (the output arrays are first touched in parallel too)
+    {
+        std::vector<u64> toff(parts_n + 1, 0), roff(parts_n + 1, 0);
+        for (u64 k = 0; k < parts_n; ++k) { toff[k + 1] = toff[k] + part[k].text.size(); roff[k + 1] = roff[k] + part[k].starts.size(); }
+        std::vector<std::thread> th;
+        for (u64 k = 0; k < parts_n; ++k)
+            th.emplace_back([&, k]() {
+                CsvPart& p = part[k];
+                if (!p.text.empty()) memcpy(out->text + toff[k], p.text.data(), p.text.size());
+                for (size_t r = 0; r < p.starts.size(); ++r) {
+                    out->row_text_starts[roff[k] + r] = toff[k] + p.starts[r];
+                    out->row_file_offsets[roff[k] + r] = p.offs[r];
+                }
+                std::vector<u8>().swap(p.text);   // release the part as soon as it is copied
+                std::vector<u64>().swap(p.starts);
+                std::vector<u64>().swap(p.offs);
+            });
+        for (auto& t : th) t.join();
     }
     out->row_file_offsets[rows] = rows ? last_end : 0;
     char* pn = out->column_names;
