@@ -243,7 +243,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8 text / u64 keys / u32 suffix indices",
+            "dtype": ("u8 text / u32 narrow keys / u32 suffix indices" if last.get("narrow_k")
+                      else "u8 text / u64 keys / u32 suffix indices"),
             "data": "synthetic",
             "config": {"workload": f"D1 uniform27 text N={N:,} (32-bit device build, libsais64-compatible 64-bit output by widening kernel) + {Q:,} batched {m}-byte queries per GPU",
                        "n_chars": N, "queries_per_gpu": Q, "pattern_len": m,
@@ -254,7 +255,7 @@ def main():
             "broadcast_ms": bcast_ms,
             "replica_query_ok": replica_ok,
             "build_stats": {k: last[k] for k in ("sigma", "bits_per_symbol", "initial_chars", "rounds", "chunk_rounds",
-                                                 "doubling_rounds", "final_depth", "radix_passes", "active_total")},
+                                                 "doubling_rounds", "final_depth", "radix_passes", "active_total", "narrow_k")},
             "roofline": {"bound": "hbm", "kernel": PASS_KERNELS[dom], "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK,
                          "traffic": pmc_traffic(N, PASS_KERNELS[dom]),
@@ -265,7 +266,7 @@ def main():
                                                             "bytes_per_launch": kind_bytes[k] / kind_launches[k],
                                                             "achieved": kind_bytes[k] / kind_ms[k] / 1e6}
                                           for k in range(4) if kind_launches[k]}},
-            "roofline_query": {"bound": "hbm", "kernel": "query_kernel", "achieved": q_achieved / 1e9, "peak": HBM_PEAK / 1e9,
+            "roofline_query": {"bound": "hbm", "kernel": "query_kernel<true>" if last.get("narrow_k") else "query_kernel<false>", "achieved": q_achieved / 1e9, "peak": HBM_PEAK / 1e9,
                                "unit": "GB/s", "frac": q_achieved / HBM_PEAK, "bytes_per_query_model": bq},
             "gate": gate,
         }

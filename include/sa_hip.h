@@ -173,12 +173,13 @@ typedef struct sa_hip_build_stats {
      * [1] top digit of a narrow sort (u32 key + u32 value out): radix_onesweep_kernel<512,0,true> from u64
      *     keys, or text_top_pass_kernel<512> from the text (text_top_pass),
      * [2] seg_onesweep_kernel<512,24,false,true> (u32 key + u32 value in and out),
-     * [3] seg_onesweep_kernel<512,24,true,true> (u32 key + u32 value in, u64 key + u32 value out) */
+     * [3] seg_onesweep_kernel<512,24,true,true>: last narrow pass (u32 key + u32 value in; out: u32 key + u32 value when
+     *     the index keeps the narrow keys (narrow_k), else rebuilt u64 key + u32 value) */
     double   pass_ms[4];
     uint64_t pass_bytes[4];      /* algorithmic bytes (read + written)                      */
     uint32_t pass_launches[4];
     uint32_t text_top_pass;      /* 1: kernel [1] was text_top_pass_kernel<512> (keys assembled from the text) */
-    uint32_t reserved_;
+    uint32_t narrow_k;           /* 1: the index keeps u32 narrow keys + 257 bucket bounds as its query key array   */
 } sa_hip_build_stats;
 int sa_hip_index_build_stats(const sa_hip_index* idx, sa_hip_build_stats* out);
 

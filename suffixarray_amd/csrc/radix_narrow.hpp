@@ -159,7 +159,8 @@ struct SegPassArgs {
     const u32* keys_in;
     const u32* vals_in;
     u32* keys_out;         // narrow keys (passes before the last)
-    u64* keys_out64;       // LAST: (bucket << 56) | (narrow key << lo_shift)
+    u64* keys_out64;       // LAST: (bucket << 56) | (narrow key << lo_shift); nullptr: the last pass too leaves narrow keys
+                           // in keys_out (the caller keeps them as they are: Builder::qkeys32)
     u32* vals_out;
     const SegPlan* plan;
     int shift;             // digit of the narrow key
@@ -276,8 +277,10 @@ __device__ __forceinline__ void seg_tile(const SegPassArgs& a, const u32 flat, c
         if (FULL || p < tile_n) {
             const u32 kk = s_keys[p];
             gidx[k] = s_gdelta[(kk >> a.shift) & a.mask] + p;
-            if (LAST) a.keys_out64[gidx[k]] = ((u64)bucket << 56) | ((u64)kk << a.lo_shift);
-            else {
+            if (LAST) {
+                if (a.keys_out64) a.keys_out64[gidx[k]] = ((u64)bucket << 56) | ((u64)kk << a.lo_shift);   // uniform branch
+                else a.keys_out[gidx[k]] = kk;
+            } else {
                 a.keys_out[gidx[k]] = kk;
                 atomicAdd(&s_whist[(kk >> a.next_shift) & a.next_mask], 1u);
             }
@@ -718,8 +721,12 @@ inline int narrow_text_histogram(RadixWorkspace& ws, NarrowWorkspace& nw, hipStr
 //                   (radix_prepare() + narrow_text_histogram() before).
 // keysA / keysB and valsA / valsB are the ping-pong buffers of the plain sort (n * 8 and n * 4 bytes);
 // narrow keys use the first n * 4 bytes of a key buffer.  Result: *keys_res (u64, full keys), *vals_res.
+// keep_narrow: the last pass does not rebuild the u64 keys; *keys_res then points at u32[n] narrow keys, the full key of
+// slot j being (bucket(j) << 56) | (narrow[j] << begin_bit) with the bucket bounds in nw.plan->bstart (8 bytes per
+// record less written here, 4 less read by whoever consumes the keys).
 inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_t stream, u64* keysA, u32* valsA, u64* keysB,
-                             u32* valsB, u32 n, int begin_bit, u64** keys_res, u32** vals_res, const TextSource* src = nullptr) {
+                             u32* valsB, u32 n, int begin_bit, u64** keys_res, u32** vals_res, const TextSource* src = nullptr,
+                             bool keep_narrow = false) {
     int rc;
     const int lo_bits = 56 - begin_bit;                       // 1 .. 32
     const int np = (lo_bits + RADIX_BITS - 1) / RADIX_BITS;   // narrow passes, 1 .. 4
@@ -778,7 +785,8 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
         const int bits_p = last ? (lo_bits - RADIX_BITS * (np - 1)) : RADIX_BITS;
         hipLaunchKernelGGL(seg_scan_kernel, dim3(RADIX), dim3(256), 0, stream, nw.hist + (size_t)p * RADIX * RADIX, nw.plan, nw.base);
         SegPassArgs a;
-        a.keys_in = kin; a.vals_in = vin; a.keys_out = kout; a.keys_out64 = reinterpret_cast<u64*>(kout); a.vals_out = vout;
+        a.keys_in = kin; a.vals_in = vin; a.keys_out = kout; a.keys_out64 = keep_narrow ? nullptr : reinterpret_cast<u64*>(kout);
+        a.vals_out = vout;
         a.plan = nw.plan;
         a.shift = RADIX_BITS * p;
         a.mask = (1u << bits_p) - 1u;
@@ -792,8 +800,9 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
         if ((rc = ws.timer.start(stream, last ? 3 : 2))) return rc;
         if (last) hipLaunchKernelGGL((seg_onesweep_kernel<512, SEG_ITEMS, true>), dim3(flat_max), dim3(512), 0, stream, a);
         else hipLaunchKernelGGL((seg_onesweep_kernel<512, SEG_ITEMS, false>), dim3(flat_max), dim3(512), 0, stream, a);
-        if ((rc = ws.timer.stop(stream, (u64)n * (last ? 20u : 16u)))) return rc;
-        ws.pass_records += n; ws.pass_bytes += (u64)n * (last ? 20u : 16u); ws.passes += 1;
+        const u64 pass_bytes = (u64)n * ((last && !keep_narrow) ? 20u : 16u);
+        if ((rc = ws.timer.stop(stream, pass_bytes))) return rc;
+        ws.pass_records += n; ws.pass_bytes += pass_bytes; ws.passes += 1;
         u32* tk = kin; kin = kout; kout = tk;
         u32* tv = vin; vin = vout; vout = tv;
     }

@@ -208,13 +208,42 @@ __global__ __launch_bounds__(256) void dir_fill_kernel(DirArgs d) {
     }
 }
 
-__global__ __launch_bounds__(BLD_BLOCK) void flags_kernel(const u64* __restrict__ keys, u32 n, u8* __restrict__ lf,
+// NARROW: the keys are the u32 narrow keys a narrow-record sort leaves behind (radix_narrow.hpp, keep_narrow): the full
+// key of slot j is (bucket(j) << 56) | (narrow[j] << lo_shift), bucket(j) = the b with bstart[b] <= j < bstart[b+1].
+// The kernel rebuilds the u64 keys in registers (4 instead of 8 bytes read per slot, and the sort's last pass has
+// 8 bytes per slot less to write); everything after the loads is the same code.
+struct NarrowKeys {
+    const u32* keys32;
+    const u32* bstart;   // [257], bstart[256] = n
+    int lo_shift;
+};
+template <bool NARROW>
+__global__ __launch_bounds__(BLD_BLOCK) void flags_kernel(const u64* __restrict__ keys, NarrowKeys nk, u32 n, u8* __restrict__ lf,
                                                           uint2* __restrict__ counts, const u32* __restrict__ apos,
                                                           const u32* __restrict__ sidx, u32* __restrict__ sa_out,
                                                           u8* __restrict__ gflags, DirArgs dirargs) {
     __shared__ u32 s_a[BLD_BLOCK / WAVE], s_h[BLD_BLOCK / WAVE];
+    __shared__ u32 s_b[NARROW ? 257 : 1];
+    if (NARROW) {
+        for (int i = threadIdx.x; i <= 256; i += BLD_BLOCK) s_b[i] = nk.bstart[i];
+        __syncthreads();
+    }
     const u64 base = (u64)blockIdx.x * BLD_TILE;
     u32 ca = 0, ch = 0;
+    u32 bkt = 0;   // NARROW: bucket of the slot looked at last; a thread's slots only move forward
+    if (NARROW) {
+        // bucket of the first slot this thread looks at: the last b with bstart[b] <= slot (empty buckets share their
+        // successor's start, so this is the non-empty one that holds the slot); later slots walk on from there
+        const u64 j0 = base + (u64)threadIdx.x * 4;
+        const u64 jf = (j0 > 0) ? j0 - 1 : 0;
+        u32 lo = 0, hi = 256;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const u32 mid = (lo + hi) >> 1;
+            if ((u64)s_b[mid] <= jf) lo = mid; else hi = mid;
+        }
+        bkt = lo;
+    }
     // four consecutive elements per thread and step: two 16-byte key loads + the two neighbouring keys instead of
     // three 8-byte loads per element, and one 4-byte store of the four flag bytes instead of four 1-byte stores
     // (the key and flag buffers are 16-byte aligned; the flag buffer carries >= 64 bytes of slack)
@@ -224,6 +253,26 @@ __global__ __launch_bounds__(BLD_BLOCK) void flags_kernel(const u64* __restrict_
         const u64 j0 = base + (u64)it * (BLD_BLOCK * 4) + (u64)threadIdx.x * 4;
         if (j0 >= n) continue;
         u64 k[6];   // keys j0-1 .. j0+4
+        if (NARROW) {
+            u32 w[6];
+            if (j0 + 4 <= n) {
+                const uint4 x = *reinterpret_cast<const uint4*>(nk.keys32 + j0);
+                w[1] = x.x; w[2] = x.y; w[3] = x.z; w[4] = x.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[1 + e] = (j0 + e < n) ? nk.keys32[j0 + e] : 0u;
+            }
+            w[0] = (j0 > 0) ? nk.keys32[j0 - 1] : 0u;
+            w[5] = (j0 + 4 < n) ? nk.keys32[j0 + 4] : 0u;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                const u64 j = j0 + e - 1;   // e == 0 at j0 == 0 is never used
+                if (j < n && !(e == 0 && j0 == 0)) {
+                    while ((u64)s_b[bkt + 1] <= j) ++bkt;   // bstart[256] = n > j
+                    k[e] = ((u64)bkt << 56) | ((u64)w[e] << nk.lo_shift);
+                } else k[e] = 0ull;
+            }
+        } else {
         if (j0 + 4 <= n) {
             const uint4 x0 = *reinterpret_cast<const uint4*>(keys + j0);
             const uint4 x1 = *reinterpret_cast<const uint4*>(keys + j0 + 2);
@@ -235,6 +284,7 @@ __global__ __launch_bounds__(BLD_BLOCK) void flags_kernel(const u64* __restrict_
         }
         k[0] = (j0 > 0) ? keys[j0 - 1] : 0ull;
         k[5] = (j0 + 4 < n) ? keys[j0 + 4] : 0ull;
+        }
         u32 fl = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -867,6 +917,12 @@ struct Builder {
     bool debug_rounds = false;
     // query acceleration (sa_query.hpp): sorted packed keys K + bucket directory
     const u64* qkeys = nullptr;   // points into keys0/keys1 (build) or keys0 (load)
+    // ... or, after a narrow-record sort (narrow_k): u32 narrow keys + the 257 bucket bounds of the top digit;
+    // key of slot j = (bucket(j) << 56) | (qkeys32[j] << q_lo_shift).  Exactly one of qkeys / qkeys32 is set.
+    const u32* qkeys32 = nullptr;
+    const u32* q_bstart = nullptr;
+    int q_lo_shift = 0;
+    bool narrow_k = true;         // SA_HIP_NARROW_K: keep the narrow keys (the last narrow pass writes 4-byte keys)
     DevBuf qdir;
     CodeMap qmap;
     int q_b = 0, q_k0 = 0, q_dbits = 0;
@@ -919,6 +975,7 @@ struct Builder {
         if (const char* e = getenv("SA_HIP_FUSE_DIR")) fuse_directory = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_NARROW")) narrow_sort = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_TEXT_PASS")) text_top_pass = atoi(e) != 0;
+        if (const char* e = getenv("SA_HIP_NARROW_K")) narrow_k = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_TINY")) tiny_finisher = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_DEBUG_ROUNDS")) debug_rounds = atoi(e) != 0;
         if (debug_rounds) { radix.debug_hook = &Builder::sort_debug_hook; radix.debug_ctx = this; }
@@ -1027,7 +1084,7 @@ struct Builder {
 
     // head/active flags over `cnt` sorted keys (+ optional round write-back), scanned counts.
     int flags_and_counts(const u64* keys, u32 cnt, u8* lf_out, const u32* apos, const u32* sidx, u32* totals_host,
-                         bool with_directory = false) {
+                         bool with_directory = false, const NarrowKeys* nk = nullptr) {
         const u32 tiles = div_up(cnt, BLD_TILE);
         DirArgs d{};
         if (with_directory) {
@@ -1043,8 +1100,12 @@ struct Builder {
             d.dstat = radix.dstat;
             SA_HIP_CHECK(hipMemsetAsync(d.gap_count, 0, 4, stream));
         }
-        hipLaunchKernelGGL(flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, keys, cnt, lf_out, counts.as<uint2>(),
-                           apos, sidx, sa, flags.as<u8>(), d);
+        if (nk)
+            hipLaunchKernelGGL(flags_kernel<true>, dim3(tiles), dim3(BLD_BLOCK), 0, stream, (const u64*)nullptr, *nk, cnt, lf_out,
+                               counts.as<uint2>(), apos, sidx, sa, flags.as<u8>(), d);
+        else
+            hipLaunchKernelGGL(flags_kernel<false>, dim3(tiles), dim3(BLD_BLOCK), 0, stream, keys, NarrowKeys{}, cnt, lf_out,
+                               counts.as<uint2>(), apos, sidx, sa, flags.as<u8>(), d);
         if (with_directory) {
             hipLaunchKernelGGL(dir_fill_kernel, dim3(1024), dim3(256), 0, stream, d);
             dir_ready = true;
@@ -1108,7 +1169,8 @@ struct Builder {
 
     // Directory by binary search (adopted indexes; a build gets it from its first flags pass)
     int build_directory() {
-        if (!qkeys || n < 2) { qkeys = nullptr; return 0; }
+        if ((!qkeys && !qkeys32) || n < 2) { qkeys = nullptr; qkeys32 = nullptr; return 0; }
+        if (qkeys32 && !dir_ready) return fail(SA_HIP_EINTERNAL, "narrow keys without a fused directory");
         if (dir_ready) {
             const u64 n16 = ((1ull << q_dbits) + 1) / 4;
             hipLaunchKernelGGL(dir_touch_kernel, dim3(stream_grid(n16, 256)), dim3(256), 0, stream, qdir.as<uint4>(), n16,
@@ -1134,6 +1196,7 @@ struct Builder {
     // Query structures for an adopted (text, SA): packed keys gathered from the text.
     int prepare_query_from_sa(const CodeMap& map, int b, u32 L) {
         qkeys = nullptr;
+        qkeys32 = nullptr;
         dir_ready = false;
         if (n < 2) return 0;
         const int k0 = choose_initial_chars(b, L);
@@ -1185,6 +1248,7 @@ struct Builder {
         stats.bits_per_symbol = (u32)b;
         sa = vals0.as<u32>();
         qkeys = nullptr;
+        qkeys32 = nullptr;
         dir_ready = false;
         if (n == 0) return finish_stats();
         if (n == 1) {
@@ -1214,20 +1278,31 @@ struct Builder {
                                fuse_hist ? radix.hist(0) : (u32*)nullptr);
         }
         u64* kres; u32* vres;
+        // the narrow keys can stay narrow when the query directory comes out of the flags pass below (the directory
+        // by binary search reads u64 keys)
+        const bool keep_narrow = narrow_path && narrow_k && fuse_directory;
+        stats.narrow_k = keep_narrow ? 1u : 0u;
         if (narrow_path) {
             TextSource src;
             src.text = text.as<u8>(); src.b = b; src.k0 = k0;
             if ((rc = radix_sort_narrow(radix, narrow, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(),
-                                        n32, begin_bit, &kres, &vres, text_pass ? &src : nullptr))) return rc;
+                                        n32, begin_bit, &kres, &vres, text_pass ? &src : nullptr, keep_narrow))) return rc;
         } else if ((rc = radix_sort_pairs(radix, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(), n32,
                                           begin_bit, 64, true, fuse_hist, &kres, &vres))) return rc;
         sa = vres;
-        qkeys = kres;   // sorted packed keys: kept for the query path (sa_query.hpp)
+        // sorted packed keys: kept for the query path (sa_query.hpp)
+        NarrowKeys nk{};
+        if (keep_narrow) {
+            qkeys32 = reinterpret_cast<const u32*>(kres);
+            q_bstart = narrow.plan->bstart;
+            q_lo_shift = begin_bit;
+            nk.keys32 = qkeys32; nk.bstart = q_bstart; nk.lo_shift = q_lo_shift;
+        } else qkeys = kres;
         qmap = map; q_b = b; q_k0 = k0;
 
         // head flags, active counts
         u32 tot[2];
-        if ((rc = flags_and_counts(kres, n32, flags.as<u8>(), nullptr, nullptr, tot, fuse_directory))) return rc;
+        if ((rc = flags_and_counts(kres, n32, flags.as<u8>(), nullptr, nullptr, tot, fuse_directory, keep_narrow ? &nk : nullptr))) return rc;
         if ((rc = check_device_status())) return rc;
         u32 M = tot[0], G = tot[1];
         u64 h = (u64)k0;

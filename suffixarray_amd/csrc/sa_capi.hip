@@ -46,13 +46,16 @@ int launch_query(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q
     a.q = Q;
     a.out = out_dev;
     a.keys = idx->b.qkeys;
+    a.keys32 = idx->b.qkeys32;
+    a.lo_shift = idx->b.q_lo_shift;
     a.dir = idx->b.qdir.as<u32>();
     a.b = idx->b.q_b; a.k0 = idx->b.q_k0; a.dbits = idx->b.q_dbits;
     SA_HIP_CHECK(hipEventRecord(idx->q_begin, idx->stream));
     if (Q) {
         u64 g = (Q + 255) / 256;
         if (g > 256u * 16u) g = 256u * 16u;
-        hipLaunchKernelGGL(query_kernel, dim3((u32)g), dim3(256), 0, idx->stream, a, idx->b.qmap);
+        if (a.keys32) hipLaunchKernelGGL(query_kernel<true>, dim3((u32)g), dim3(256), 0, idx->stream, a, idx->b.qmap);
+        else hipLaunchKernelGGL(query_kernel<false>, dim3((u32)g), dim3(256), 0, idx->stream, a, idx->b.qmap);
     }
     SA_HIP_CHECK(hipEventRecord(idx->q_end, idx->stream));
     SA_HIP_CHECK(hipGetLastError());

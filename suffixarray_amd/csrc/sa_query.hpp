@@ -13,6 +13,9 @@
 //                kept instead of discarded; b bits per character after alphabet compaction).  A
 //                search step is ONE aligned 8-byte load, no indirection, and the last three steps
 //                of a descent fall into one 64-byte sector.
+//                After a narrow-record sort (keys of <= 40 bits) K is u32[n] instead: (u32)(key >> (64 - key bits)), i.e.
+//                the key without (all of) its top 8 bits, which are the same for every slot of a directory bucket (dbits >= 8) and therefore
+//                never need to be looked at inside one: 4-byte probes, four steps per sector (query_kernel<true>).
 //   dir  u32[2^dbits + 1]  bucket directory over the top dbits of K (first slot of every bucket):
 //                one load replaces the top ~24 levels of the descent (it stays resident in the
 //                Infinity Cache across the batch).
@@ -21,6 +24,7 @@
 // The lower-bound descent remembers the tightest strictly-greater slot, so the upper bound
 // starts inside [lb, hi_strict).
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 #include "sa_build.hpp"
 
@@ -88,9 +92,14 @@ struct QueryArgs {
     const u64* keys;        // K
     const u32* dir;         // bucket directory, 2^dbits + 1 entries
     int b, k0, dbits;
+    const u32* keys32;      // NARROW: K[j] = (top digit of j's directory bucket << 56) | (keys32[j] << lo_shift)
+    int lo_shift;
 };
 
+template <bool NARROW>
 __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
+    using KT = typename std::conditional<NARROW, u32, u64>::type;
+    const KT* __restrict__ K = NARROW ? reinterpret_cast<const KT*>(a.keys32) : reinterpret_cast<const KT*>(a.keys);
     __shared__ u16 s_map[256];
     s_map[threadIdx.x] = map.code[threadIdx.x];
     __syncthreads();
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
         // ---- phase 1: narrow to the slots whose first P characters equal the pattern's -----------
         u64 lo = 0, hi = a.n;      // lb and ub both lie in [lo, hi]
         bool exact = false;        // the K range IS the answer (whole pattern packed)
-        if (a.keys) {
+        if (K) {
             int P = 0;
             u64 key_lo = 0;
             int sh = 64;
@@ -127,12 +136,24 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
                 u64 l = a.dir[bl], h = a.dir[bl + 1];
                 u64 h_strict = (bh == bl) ? h : a.dir[bh + 1];   // first slot known to be > key_hi
                 const u64 h2_lo = (bh == bl) ? 0 : a.dir[bh];
+                // thresholds in the domain of the stored keys.  NARROW: every slot of a directory bucket has the
+                // bucket's top 8 key bits (dbits >= 8), so inside bucket bl "K < key_lo" is a comparison of the
+                // bits below them, and "K > key_hi" can only hold when key_hi has the same top digit; the bits
+                // below lo_shift are zero in K and in key_lo and all ones in key_hi (sh >= lo_shift).
+                KT t_lo, t_hi1, t_hi2;
+                if (NARROW) {
+                    // the stored form is (u32)(key >> lo_shift): keys of 40 bits lose their top digit in the
+                    // truncation, shorter ones keep (part of) it -- the thresholds are truncated the same way
+                    t_lo = (KT)(key_lo >> a.lo_shift);
+                    t_hi2 = (KT)(key_hi >> a.lo_shift);
+                    t_hi1 = ((key_lo >> 56) == (key_hi >> 56)) ? t_hi2 : (KT)~(KT)0;
+                } else { t_lo = (KT)key_lo; t_hi1 = t_hi2 = (KT)key_hi; }
                 // first slot with K >= key_lo
                 while (l < h) {
                     const u64 mid = (l + h) >> 1;
-                    const u64 k = a.keys[mid];
-                    if (k < key_lo) l = mid + 1;
-                    else { h = mid; if (k > key_hi) h_strict = mid; }
+                    const KT k = K[mid];
+                    if (k < t_lo) l = mid + 1;
+                    else { h = mid; if (k > t_hi1) h_strict = mid; }
                 }
                 lo = l;
                 // first slot with K > key_hi, inside [max(lo, dir[bh]), h_strict]
@@ -140,7 +161,7 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
                 u64 h2 = h_strict;
                 while (l2 < h2) {
                     const u64 mid = (l2 + h2) >> 1;
-                    if (a.keys[mid] <= key_hi) l2 = mid + 1; else h2 = mid;
+                    if (K[mid] <= t_hi2) l2 = mid + 1; else h2 = mid;
                 }
                 hi = l2;
                 exact = ((u32)P == c);

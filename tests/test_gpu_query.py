@@ -251,3 +251,40 @@ def test_query_hits_equals_batch_plus_range(gpu, oracle):
                 assert hits.size == take, (p, cap)
                 if take:
                     assert np.array_equal(hits, idx.sa_range(int(f), take))
+
+
+def test_narrow_key_array_matches_wide_key_array(gpu, oracle, monkeypatch):
+    """After a narrow-record sort the index keeps u32 narrow keys + 257 bucket bounds as its query key array
+    (SA_HIP_NARROW_K, default on) instead of rebuilt u64 keys: same suffix array, same directory, same ranges --
+    against the u64 form and against the oracle (engine.c:869-918).  Patterns of 1..40 bytes: one- and
+    two-character patterns span several top digits, long ones go on into the text comparison; a skewed alphabet
+    leaves most top-digit buckets empty; forced key lengths give narrow keys of fewer than 32 bits."""
+    from suffixarray_amd import synth
+    rng = np.random.default_rng(5)
+    skew = rng.choice(np.array([97, 98, 99, 100, 122], dtype=np.uint8), 5_000_000, p=[0.9, 0.04, 0.03, 0.02, 0.01])
+    two = rng.choice(np.array([97, 122], dtype=np.uint8), 4_500_000)
+    runs = [(synth.d1_uniform27(4_500_001), 0, 0), (synth.d1_uniform27(5_000_000), 7, 0), (synth.d1_uniform27(5_000_000), 0, 32),
+            (skew, 13, 0), (skew, 5, 0), (two, 20, 0), (two, 9, 6), (synth.d2_words(6_000_000), 8, 0),
+            (rng.integers(0, 256, 4_500_000).astype(np.uint8), 0, 4)]
+    for t, k0, L in runs:
+        if k0:
+            monkeypatch.setenv("SA_HIP_INITIAL_CHARS", str(k0))
+        else:
+            monkeypatch.delenv("SA_HIP_INITIAL_CHARS", raising=False)
+        pats = cases.query_patterns(t, 3000, rng)
+        pats += [bytes([c]) for c in np.unique(t)[:8]] + [bytes(t[p:p + m]) for p in (0, 17, t.size - 9) for m in (1, 2, 3, 8, 9)]
+        got, sas = {}, {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SA_HIP_NARROW_K", mode)
+            with gpu.DeviceIndex(t.size, 0) as idx:
+                idx.build(t, L)
+                st = idx.build_stats()
+                assert st["narrow_k"] == (1 if mode == "1" else 0), st
+                assert st["pass_launches"][3] == 1, st
+                assert idx.verify() == 0, st
+                sas[mode] = idx.sa_u32().copy()
+                got[mode] = idx.query_batch(pats)
+        assert np.array_equal(sas["1"], sas["0"]), (t.size, k0, L)
+        assert np.array_equal(got["1"], got["0"]), (t.size, k0, L)
+        exp = oracle.query_batch(t, sas["1"], L if L else 0xFFFFFFFF, pats)
+        assert np.array_equal(got["1"], exp), (t.size, k0, L)
