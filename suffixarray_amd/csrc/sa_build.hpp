@@ -163,7 +163,7 @@ __global__ __launch_bounds__(BLD_BLOCK) void keygen_kernel(const u8* __restrict_
 // dir[bkt] = first slot whose key has top-dbits >= bkt.  Slot j owns the buckets (top(K[j-1]), top(K[j])];
 // runs of up to DIR_INLINE buckets are written here, longer ones (unused codes of the compacted
 // alphabet leave holes of up to 2^dbits / 8 buckets) are queued for dir_fill_kernel.
-constexpr u32 DIR_INLINE = 8;
+constexpr u32 DIR_INLINE = 40;   // 8 queued the (2^(dbits-25) * 8 + 1)-bucket holes behind every 5-character prefix of a 27-letter text: 531 441 atomics on one counter, +5 ms
 constexpr u32 DIR_PIECE = 1u << 14;
 struct DirArgs {
     u32* dir;        // [2^dbits + 1], or nullptr
@@ -1147,8 +1147,10 @@ struct Builder {
 
     // Bucket directory over the top q_dbits bits of the sorted keys (qkeys must be set), built in two
     // levels: a 2^14-bucket directory by full binary searches, then the fine one inside its buckets.
-    // Default q_dbits = log2(n) - 6 (about 64 slots per bucket: one more millisecond of build at
-    // n = 1e9 buys 20 % on every query batch); SA_HIP_DIR_BITS overrides.
+    // Default q_dbits = log2(n) - 4, at most 27 (about 16 slots per bucket = one 64-byte sector of narrow keys: the
+    // key search of a query stays inside one or two sectors; at n = 1e9, per 1M-query batch, 24 / 25 / 26 / 27 / 28
+    // bits: 0.169 / 0.148 / 0.125 / 0.109 / 0.101 ms, for +0.2 ms of build per bit -- the directory entries are
+    // written by the flags pass, 4 bytes each, 268 MB at 26 bits); SA_HIP_DIR_BITS overrides.
     // qdir layout: fine directory u32[nb] | coarse directory u32[ncb] (two-level build only) | gap queue
     static int dir_coarse_bits(int d) { return d > 16 ? 14 : 0; }
     static size_t dir_gap_offset(u64 nb) { return (((size_t)nb + (1u << 14) + 1) * 4 + 15) & ~(size_t)15; }
@@ -1158,9 +1160,9 @@ struct Builder {
     int directory_layout(u64 count) {
         int lg = 0;
         while ((1ull << lg) < count) ++lg;
-        int d = lg - 6;
+        int d = lg - 4;
         if (d < 8) d = 8;
-        if (d > 24) d = 24;
+        if (d > 27) d = 27;
         if (const char* e = getenv("SA_HIP_DIR_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 28) d = v; }
         q_dbits = d;
         const u64 nb = (1ull << d) + 1;
@@ -1172,6 +1174,8 @@ struct Builder {
         if ((!qkeys && !qkeys32) || n < 2) { qkeys = nullptr; qkeys32 = nullptr; return 0; }
         if (qkeys32 && !dir_ready) return fail(SA_HIP_EINTERNAL, "narrow keys without a fused directory");
         if (dir_ready) {
+            // (also worth it beyond the cache's 256 MiB: at 26 bits the first batch after a build takes 0.125 ms with
+            //  this read, 0.147 ms without, and the build time is the same within the noise)
             const u64 n16 = ((1ull << q_dbits) + 1) / 4;
             hipLaunchKernelGGL(dir_touch_kernel, dim3(stream_grid(n16, 256)), dim3(256), 0, stream, qdir.as<uint4>(), n16,
                                reinterpret_cast<u32*>(small.as<u8>() + 3588));
