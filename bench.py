@@ -267,7 +267,9 @@ def main():
                                                             "achieved": kind_bytes[k] / kind_ms[k] / 1e6}
                                           for k in range(4) if kind_launches[k]}},
             "roofline_query": {"bound": "hbm", "kernel": "query_kernel<true>" if last.get("narrow_k") else "query_kernel<false>", "achieved": q_achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                               "unit": "GB/s", "frac": q_achieved / HBM_PEAK, "bytes_per_query_model": bq},
+                               "unit": "GB/s", "frac": q_achieved / HBM_PEAK, "bytes_per_query_model": bq,
+                               "note": "bytes of the REFERENCE algorithm per query (SURVEY 8d: 2*ceil(log2 N)*(4+m)); the directory and the "
+                                       "key array replace most of its probes, so the kernel moves far fewer real bytes and this figure can exceed the peak"},
             "gate": gate,
         }
         if world == 1 and not args.no_cpu_baseline:
