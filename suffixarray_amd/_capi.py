@@ -351,24 +351,45 @@ def get_substring_positions(text, sa, max_suffix_length, substring):
     return (r.first, r.second)
 
 
-def csv_extract_column(path, column):
-    """Native RFC-4180 column extractor -> (columns, text bytes, row_text_starts, row_file_offsets)."""
+class _CsvOwner:
+    """Keeps the malloc'ed arrays of one sa_hip_csv_column alive for the numpy views made of them."""
+
+    def __init__(self, col):
+        self.col = col
+
+    def __del__(self):
+        try:
+            lib().sa_hip_csv_free(C.byref(self.col))
+        except Exception:
+            pass
+
+
+def _view(owner, ptr, count, ctype, dtype):
+    if not count:
+        return np.zeros(0, dtype)
+    buf = (ctype * count).from_address(C.cast(ptr, C.c_void_p).value)
+    buf._owner = owner   # the view's base is this ctypes array: the owner lives as long as any view does
+    return np.frombuffer(buf, dtype=dtype)
+
+
+def csv_extract_column(path, column, copy=True):
+    """Native RFC-4180 column extractor -> (columns, text, row_text_starts, row_file_offsets).
+    copy=True: text as bytes, the offsets as numpy arrays of their own.  copy=False: text as a uint8 array and the
+    offsets as views of the arrays the extractor allocated (freed when the last view goes): no second copy of the
+    ~2 bytes + 16 bytes per row that a 50M-row file yields (0.3 s of the 0.9 s the copying form takes)."""
     col = CsvColumn()
     check(lib().sa_hip_csv_extract_column(os.fsencode(path), column.encode("utf-8"), C.byref(col)))
-    try:
-        text = C.string_at(col.text, col.text_len) if col.text_len else b""
-        # one copy each out of the malloc'ed arrays (they are freed below); offsets are < 2^63: viewed as int64
-        i64p = C.POINTER(C.c_int64)
-        starts = np.ctypeslib.as_array(C.cast(col.row_text_starts, i64p), shape=(col.num_rows,)).copy() \
-            if col.num_rows else np.zeros(0, np.int64)
-        offs = np.ctypeslib.as_array(C.cast(col.row_file_offsets, i64p), shape=(col.num_rows + 1,)).copy()
-        names, p = [], col.column_names
-        for _ in range(col.num_columns):
-            s = C.string_at(p)
-            names.append(s.decode("utf-8"))
-            p += len(s) + 1
-    finally:
-        lib().sa_hip_csv_free(C.byref(col))
+    owner = _CsvOwner(col)
+    names, p = [], col.column_names
+    for _ in range(col.num_columns):
+        s = C.string_at(p)
+        names.append(s.decode("utf-8"))
+        p += len(s) + 1
+    text = _view(owner, col.text, col.text_len, C.c_uint8, np.uint8)
+    starts = _view(owner, col.row_text_starts, col.num_rows, C.c_int64, np.int64)   # offsets are < 2^63: viewed as int64
+    offs = _view(owner, col.row_file_offsets, col.num_rows + 1, C.c_int64, np.int64)
+    if copy:
+        return names, text.tobytes(), starts.copy(), offs.copy()
     return names, text, starts, offs
 
 

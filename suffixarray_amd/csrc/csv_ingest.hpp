@@ -14,6 +14,7 @@
 
 #include <sched.h>
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -165,6 +166,46 @@ inline void csv_parse_range(const u8* d, u64 n, u64 begin, u64 hi, u32 ci, CsvPa
     part.starts.reserve((size_t)((hi - begin) / 24 + 16));
     part.offs.reserve((size_t)((hi - begin) / 24 + 16));
     while (cur.i < hi) {
+        // Fast path: a row without a quote character (and without a bare '\r') needs no state machine -- it ends at
+        // the next '\n', its fields are separated by every ','.  Three memchr sweeps over the ~30 bytes of the row
+        // + one per comma up to the wanted field, against ~250 ns per row in the run-based parser below.
+        {
+            const u64 i = cur.i;
+            const u8* p = d + i;
+            const u8* nl = static_cast<const u8*>(memchr(p, '\n', n - i));
+            const u64 len = nl ? (u64)(nl - p) : n - i;
+            if (!memchr(p, '"', len)) {
+                const u8* cr = static_cast<const u8*>(memchr(p, '\r', len));
+                if (!cr || (u64)(cr - p) == len - 1) {   // no '\r', or the one of a CRLF / a last '\r' at the end of the file
+                    const u64 clen = cr ? len - 1 : len;
+                    const u64 next = nl ? i + len + 1 : n;
+                    cur.i = next;
+                    if (clen == 0) continue;   // blank line
+                    const u8* f = p;
+                    const u8* fend = p + clen;
+                    u32 k = 0;
+                    for (; k < ci; ++k) {
+                        const u8* c = static_cast<const u8*>(memchr(f, ',', (size_t)(fend - f)));
+                        if (!c) break;
+                        f = c + 1;
+                    }
+                    const u64 tpos = part.text.size();
+                    if (k == ci) {
+                        const u8* c = static_cast<const u8*>(memchr(f, ',', (size_t)(fend - f)));
+                        const u8* g = c ? c : fend;
+                        const u64 flen = (u64)(g - f);
+                        part.text.resize(tpos + flen + 1);
+                        u8* dst = part.text.data() + tpos;
+                        for (u64 q = 0; q < flen; ++q) { const u8 ch = f[q]; dst[q] = (u8)(ch + (((u8)(ch - 65u) < 26u) ? 32u : 0u)); }
+                        dst[flen] = '\n';
+                    } else part.text.push_back('\n');
+                    part.starts.push_back(tpos);
+                    part.offs.push_back(i);
+                    part.last_end = next;
+                    continue;
+                }
+            }
+        }
         const u64 tpos = part.text.size();
         const u32 nf = csv_parse_record_into(cur, ci, part.text, &rs, &re, &f0e);
         if (nf == 1 && f0e) continue;  // blank line (nothing was appended)
@@ -180,6 +221,15 @@ inline void csv_parse_range(const u8* d, u64 n, u64 begin, u64 hi, u32 ci, CsvPa
 // terminator, so every worker can find the first row that starts inside its range on its own.
 inline int csv_extract_column(const char* path, const char* column, sa_hip_csv_column* out) {
     memset(out, 0, sizeof *out);
+    // SA_HIP_CSV_TIMING=1: phase times on stderr
+    const bool timing = getenv("SA_HIP_CSV_TIMING") && atoi(getenv("SA_HIP_CSV_TIMING")) != 0;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sa_hip csv] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(SA_HIP_EINVAL, "sa_hip_csv_extract_column: cannot open file", path);
     struct stat sb;
@@ -220,6 +270,7 @@ inline int csv_extract_column(const char* path, const char* column, sa_hip_csv_c
             th.emplace_back([&, k]() { u64 c = 0; for (u64 i = lo[k]; i < lo[k + 1]; ++i) c += (d[i] == '"'); quotes[k] = c; });
         for (auto& t : th) t.join();
     }
+    lap("quote parity (first touch)");
     // start of the first record of every range: after the first newline outside quotes at or after lo[k]
     // (a record that starts exactly at lo[k] is recognised by the terminator just before it)
     std::vector<u64> begin(parts_n + 1, n);
@@ -252,6 +303,7 @@ inline int csv_extract_column(const char* path, const char* column, sa_hip_csv_c
             th.emplace_back([&, k]() { if (begin[k] < begin[k + 1]) csv_parse_range(d, n, begin[k], begin[k + 1], (u32)ci, part[k]); });
         for (auto& t : th) t.join();
     }
+    lap("parse");
     munmap(map, n);
 
     u64 tlen = 0, rows = 0, last_end = 0;
@@ -290,6 +342,7 @@ inline int csv_extract_column(const char* path, const char* column, sa_hip_csv_c
             });
         for (auto& t : th) t.join();
     }
+    lap("merge into output arrays");
     out->row_file_offsets[rows] = rows ? last_end : 0;
     char* pn = out->column_names;
     for (auto& h : header) { memcpy(pn, h.c_str(), h.size() + 1); pn += h.size() + 1; }

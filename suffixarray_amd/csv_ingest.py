@@ -12,7 +12,24 @@ from .index import _ascii_lower
 
 
 class ColumnText:
-    __slots__ = ("columns", "text", "text_row_starts", "row_file_offsets")
+    """columns, text (bytes), text_row_starts, row_file_offsets.  text_array is the same text as a uint8 array; the
+    native extractor fills only that (a view of its own buffer) and `text` is made from it on first use."""
+    __slots__ = ("columns", "_text", "text_array", "text_row_starts", "row_file_offsets")
+
+    def __init__(self):
+        self._text = None
+        self.text_array = None
+
+    @property
+    def text(self):
+        if self._text is None and self.text_array is not None:
+            self._text = self.text_array.tobytes()
+        return self._text
+
+    @text.setter
+    def text(self, value):
+        self._text = value
+        self.text_array = np.frombuffer(value, dtype=np.uint8)
 
 
 def _parse_rows(data: bytes):
@@ -65,11 +82,11 @@ def extract_column(filename: str, search_column: str) -> ColumnText:
     machine in Python and serves as its reference in the tests."""
     from . import _capi
     try:
-        names, text, starts, offs = _capi.csv_extract_column(filename, search_column)
+        names, text, starts, offs = _capi.csv_extract_column(filename, search_column, copy=False)
     except _capi.SaHipError as e:
         raise ValueError(str(e))
     out = ColumnText()
-    out.columns, out.text, out.text_row_starts, out.row_file_offsets = names, text, starts, offs
+    out.columns, out.text_array, out.text_row_starts, out.row_file_offsets = names, text, starts, offs
     return out
 
 

@@ -94,9 +94,11 @@ cdef class SuffixArray:
             self._csv_fh.close()
             self._csv_mm = None
 
-    cdef _set_text(self, bytes text):
-        cdef uint64_t n = len(text)
-        cdef const uint8_t* p = <const uint8_t*>(<const char*>text)
+    cdef _set_text(self, text):
+        """text: bytes or a C-contiguous uint8 array (the CSV extractor's buffer, not copied)"""
+        cdef const uint8_t[::1] mv = text
+        cdef uint64_t n = mv.shape[0]
+        cdef const uint8_t* p = &mv[0] if n else NULL
         cdef int rc
         cdef uint32_t L = self.max_suffix_length
         if n > 0xFFFFFFFE:
@@ -134,7 +136,7 @@ cdef class SuffixArray:
         self.columns = col.columns
         self._row_starts = col.text_row_starts
         self._row_file_offsets = col.row_file_offsets
-        self._set_text(col.text)
+        self._set_text(col.text_array)   # a view of the extractor's own buffer: no copy
         self._mode = "csv"
 
     def query_ranges(self, substrings):
