@@ -107,6 +107,36 @@ def test_csv_native_matches_python_reference(tmp_path, capi):
     assert data.startswith(b"id,company_name,country\n") and b'", Inc."' not in data and b', Inc."' in data
 
 
+def test_csv_native_randomized_against_python_reference(tmp_path, capi, monkeypatch):
+    """Random small CSV files built from the pieces that steer the two native paths (rows without a quote character go
+    through memchr sweeps, the others through the state machine): bare CR, CRLF, blank lines, rows with fewer fields than
+    the wanted column, quoted fields with commas / newlines / doubled quotes, a last row without a terminator; 1 and 3
+    worker threads (tiny files give one part; the range splitting is covered by the 20 000-row file above)."""
+    from suffixarray_amd.csv_ingest import extract_column, extract_column_py
+    rng = np.random.default_rng(17)
+    atoms = [b"abc", b"X", b"", b"Hello World", b'"q,1"', b'"two\nlines"', b'"say ""hi"""', b'""', b"a b", b"Z9"]
+    eols = [b"\n", b"\n", b"\n", b"\r\n", b"\r", b"\n\n", b"\r\n\r\n"]
+    p = tmp_path / "r.csv"
+    for trial in range(150):
+        rows = [b"c0,c1,c2"]
+        for _ in range(int(rng.integers(0, 12))):
+            nf = int(rng.integers(1, 5))
+            rows.append(b",".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(nf)))
+        data = b""
+        for r in rows:
+            data += r + eols[int(rng.integers(0, len(eols)))]
+        if trial % 3 == 0:
+            data = data.rstrip(b"\r\n") if len(rows) > 1 else data   # last row without a terminator
+        p.write_bytes(data)
+        for threads in ("1", "3"):
+            monkeypatch.setenv("SA_HIP_CSV_THREADS", threads)
+            for col in ("c0", "c1", "c2"):
+                a, b = extract_column(str(p), col), extract_column_py(str(p), col)
+                assert a.text == b.text, (trial, col, data)
+                assert np.array_equal(a.text_row_starts, b.text_row_starts), (trial, col, data)
+                assert np.array_equal(a.row_file_offsets, b.row_file_offsets), (trial, col, data)
+
+
 def test_csv_ingest(tmp_path):
     from suffixarray_amd.csv_ingest import extract_column
     p = tmp_path / "c.csv"
