@@ -22,6 +22,15 @@ for c in range(cases):
     k0 = int(rng.integers(max(1, (9 + b - 1) // b), kmax + 1))
     L = int(rng.choice([0, 0, 3, 6, 32]))
     res = {}
+    # query parity rides along: the narrow modes keep u32 narrow keys as the query key array, the plain one u64 keys
+    pats = []
+    for i in range(2000):
+        m = int(rng.integers(1, 24))
+        if i % 2 == 0:
+            q = int(rng.integers(0, n - m))
+            pats.append(bytes(t[q:q + m]))
+        else:
+            pats.append(bytes(rng.choice(syms, m)))
     for mode in ("text", "keys", "plain"):
         os.environ["SA_HIP_NARROW"] = "0" if mode == "plain" else "1"
         os.environ["SA_HIP_TEXT_PASS"] = "1" if mode == "text" else "0"
@@ -30,12 +39,14 @@ for c in range(cases):
             idx.build(t, L)
             st = idx.build_stats()
             v = idx.verify()
-            res[mode] = (idx.sa_u32().copy(), v, st)
+            res[mode] = (idx.sa_u32().copy(), v, st, idx.query_batch(pats))
     same = np.array_equal(res["text"][0], res["plain"][0]) and np.array_equal(res["keys"][0], res["plain"][0])
+    same = same and np.array_equal(res["text"][3], res["plain"][3]) and np.array_equal(res["keys"][3], res["plain"][3])
     used = res["text"][2]["pass_launches"][2] + res["text"][2]["pass_launches"][3]
     ok = same and all(res[m][1] == 0 for m in res)
     bad += not ok
-    print("case %2d sigma %3d b %d k0 %2d L %2d n %8d narrow launches %d text_pass %d rounds %2d -> %s" % (
-        c, sigma, b, res["text"][2]["initial_chars"], L, n, used, res["text"][2]["text_top_pass"], res["text"][2]["rounds"], "ok" if ok else "MISMATCH"), flush=True)
+    print("case %2d sigma %3d b %d k0 %2d L %2d n %8d narrow launches %d text_pass %d narrow_k %d rounds %2d -> %s" % (
+        c, sigma, b, res["text"][2]["initial_chars"], L, n, used, res["text"][2]["text_top_pass"], res["text"][2]["narrow_k"],
+        res["text"][2]["rounds"], "ok" if ok else "MISMATCH"), flush=True)
 print("FAILED %d" % bad if bad else "ALL OK")
 sys.exit(1 if bad else 0)
