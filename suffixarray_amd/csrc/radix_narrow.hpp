@@ -396,10 +396,10 @@ __global__ __launch_bounds__(256) void top_hist_kernel(const u8* __restrict__ te
         sync_lds();
     };
     if (s_lo >= s_hi) return;
-    u32 cur = chunk_of_tile((u32)((s_lo * SPAN) >> g.tile_shift), g.tpc);
+    u32 cur = chunk_of_tile((u32)((s_lo * SPAN) / g.tile), g.tpc);
     for (u64 sp = s_lo; sp < s_hi; ++sp) {
         const u64 base = sp * SPAN;
-        const u32 c = chunk_of_tile((u32)(base >> g.tile_shift), g.tpc);   // a chunk is a whole number of 8192-record tiles = spans
+        const u32 c = chunk_of_tile((u32)(base / g.tile), g.tpc);   // a chunk is a whole number of tiles (8192 or 12288 records) = spans
         if (c != cur) { flush(cur); cur = c; }
         const u64 p0 = base + (u64)threadIdx.x * 16;
         if (p0 < n) {
@@ -446,6 +446,14 @@ struct TextPassArgs {
     u32 incl_mask;
 };
 constexpr int TEXT_HALO = 64;   // >= k0 - 1 (k0 * b <= 40)
+// positions per thread of the text-sourced top-digit pass.  24 (tiles of 12288 as in the narrow passes: 118 VGPRs, 71 KB of
+// LDS, two workgroups per CU) measured 3.67 against 3.61 ms for 16 (three workgroups) on the same box: unlike the narrow
+// passes this one does not live on bytes in flight, it is bound by its per-record work.
+#ifndef SA_TEXT_ITEMS
+#define SA_TEXT_ITEMS 16
+#endif
+constexpr int TEXT_ITEMS = SA_TEXT_ITEMS;
+constexpr u32 TEXT_TILE = 512u * TEXT_ITEMS;
 
 // acc |= x << s (s uniform), accumulator updated in place
 __device__ __forceinline__ void shl_or_inplace(u32& acc, u32 x, int s) {
@@ -459,9 +467,9 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
                                               const u32 tile_n, u32* s_keys, u32* s_whist, u32* s_gdelta, u32* s_wsum,
                                               u8* s_code, const u8* s_map) {
     constexpr int WAVES = BLOCK / WAVE;
-    constexpr int ITEMS = SORT_ITEMS;
+    constexpr int ITEMS = TEXT_ITEMS;
     constexpr u32 TILE = BLOCK * ITEMS;
-    static_assert(TILE == BLOCK * 16, "one 16-byte text load per thread");
+    static_assert(TILE % 16 == 0, "16-byte text loads");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 first_tile = chunk * a.g.tpc;
     const u64 tile_base = (u64)tile * TILE;
@@ -487,7 +495,9 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
         }
         *reinterpret_cast<uint4*>(s_code + local) = make_uint4(o[0], o[1], o[2], o[3]);
     };
-    if (FULL) stage16((u32)tid * 16u, std::false_type{}); else stage16((u32)tid * 16u, std::true_type{});
+    for (u32 local = (u32)tid * 16u; local < TILE; local += BLOCK * 16u) {
+        if (FULL) stage16(local, std::false_type{}); else stage16(local, std::true_type{});
+    }
     if (tid < TEXT_HALO / 16) stage16(TILE + (u32)tid * 16u, std::true_type{});
     __syncthreads();
 
@@ -613,9 +623,9 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
 
 // 79 VGPRs and 50 KB of LDS: three workgroups (24 waves) per CU
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, 6) void text_top_pass_kernel(TextPassArgs a) {
+__global__ __launch_bounds__(BLOCK, (TEXT_ITEMS > 16) ? 4 : 6) void text_top_pass_kernel(TextPassArgs a) {
     constexpr int WAVES = BLOCK / WAVE;
-    constexpr u32 TILE = BLOCK * SORT_ITEMS;
+    constexpr u32 TILE = BLOCK * TEXT_ITEMS;
     __shared__ __attribute__((aligned(16))) u32 s_keys[TILE];
     __shared__ u32 s_whist[WAVES * RADIX];
     __shared__ u32 s_gdelta[RADIX];
@@ -701,7 +711,7 @@ inline int narrow_text_histogram(RadixWorkspace& ws, NarrowWorkspace& nw, hipStr
                                  u32 n, int b) {
     nw.map_host = map;
     SA_HIP_CHECK(hipMemcpyAsync(nw.map_dev, nw.map_host.code, sizeof(CodeMap), hipMemcpyHostToDevice, stream));
-    const SortGeom g = make_geom(n, ws.tile());
+    const SortGeom g = make_geom(n, TEXT_TILE);   // the chunks of text_top_pass_kernel (its tile is not a power of two: tile_shift unused)
     const u32 spans = div_up(n, 4096);
     const dim3 grid(spans < 2048u ? spans : 2048u), block(256);
     switch ((8 + b - 1) / b) {
@@ -730,7 +740,7 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
     int rc;
     const int lo_bits = 56 - begin_bit;                       // 1 .. 32
     const int np = (lo_bits + RADIX_BITS - 1) / RADIX_BITS;   // narrow passes, 1 .. 4
-    const SortGeom g = make_geom(n, ws.tile());
+    const SortGeom g = make_geom(n, src ? TEXT_TILE : ws.tile());
     SA_HIP_CHECK(hipMemsetAsync(nw.hist, 0, NarrowWorkspace::hist_bytes(), stream));
     SA_HIP_CHECK(hipMemsetAsync(nw.tickets, 0, (size_t)NARROW_MAX_PASSES * NCHUNK * sizeof(u32), stream));
 
