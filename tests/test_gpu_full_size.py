@@ -125,17 +125,19 @@ def test_beyond_int32_max_3e9_verified(gpu, monkeypatch):
     t = synth.d1_uniform27(n)
     # both sort plans beyond 2^31 records: the build's own choice (40-bit keys in narrow records: positions and
     # bucket offsets above INT32_MAX), then the 12-byte-record plan
+    buf, off = synth.query_batch(t, 20000, 16)
     with gpu.DeviceIndex(n, 0) as idx:
         idx.build(t)
         st = idx.build_stats()
-        assert st["pass_launches"][2] > 0 and idx.verify() == 0, st
+        assert st["pass_launches"][2] > 0 and st["narrow_k"] == 1 and idx.verify() == 0, st
+        got_narrow = idx.query_batch((buf, off))   # u32 narrow key array, 27-bit directory, slots beyond 2^31
     monkeypatch.setenv("SA_HIP_NARROW", "0")
     with gpu.DeviceIndex(n, 0) as idx:
         idx.build(t)
         st = idx.build_stats()
         assert st["pass_launches"][0] > 0 and idx.verify() == 0, st
-        buf, off = synth.query_batch(t, 20000, 16)
         got = idx.query_batch((buf, off))
+        assert np.array_equal(got, got_narrow)
         pats = buf.reshape(-1, 16)
         for i in np.random.default_rng(0).integers(0, 20000, 200):
             f, s = int(got["first"][i]), int(got["second"][i])
