@@ -1041,17 +1041,28 @@ struct Builder {
         return 0;
     }
 
+    // the totals and, in the same synchronisation, the sort's device status (check_device_status() looks at this copy:
+    // one host round trip per flags pass instead of two)
+    DeviceStatus status_seen{};
+    bool status_fresh = false;
     int read_totals(u32* totals_host) {
         SA_HIP_CHECK(hipMemcpyAsync(totals_host, small.as<u8>() + 2048, 2 * sizeof(u32), hipMemcpyDeviceToHost, stream));
+        SA_HIP_CHECK(hipMemcpyAsync(&status_seen, radix.dstat, sizeof status_seen, hipMemcpyDeviceToHost, stream));
         SA_HIP_CHECK(hipStreamSynchronize(stream));
+        status_fresh = true;
         return 0;
     }
     u32* totals_dev() { return reinterpret_cast<u32*>(small.as<u8>() + 2048); }
 
     int check_device_status() {
         DeviceStatus st;
-        SA_HIP_CHECK(hipMemcpyAsync(&st, radix.dstat, sizeof st, hipMemcpyDeviceToHost, stream));
-        SA_HIP_CHECK(hipStreamSynchronize(stream));
+        if (status_fresh) {   // read together with the totals of the pass that has just been synchronised
+            st = status_seen;
+            status_fresh = false;
+        } else {
+            SA_HIP_CHECK(hipMemcpyAsync(&st, radix.dstat, sizeof st, hipMemcpyDeviceToHost, stream));
+            SA_HIP_CHECK(hipStreamSynchronize(stream));
+        }
         if (st.error != 0) {
             (void)hipMemsetAsync(radix.dstat, 0, sizeof(DeviceStatus), stream);
             return fail(SA_HIP_EINTERNAL, "device look-back spin limit expired");
