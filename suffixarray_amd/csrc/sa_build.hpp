@@ -24,6 +24,7 @@
 
 #include "common.hpp"
 #include "radix_narrow.hpp"
+#include "round_sort.hpp"
 
 namespace sa {
 
@@ -914,6 +915,9 @@ struct Builder {
     bool narrow_sort = true;          // SA_HIP_NARROW: 8-byte records for initial keys of <= 40 bits (radix_narrow.hpp)
     DevBuf partial, dbg, done;
     bool tiny_finisher = true;        // SA_HIP_TINY: direct-comparison finisher for groups of <= 8
+    bool local_rounds = true;         // SA_HIP_LOCAL_ROUNDS: rounds sorted group-wise in LDS (round_sort.hpp)
+    DevBuf gstart, loc_tiles, big_keys, big_vals;
+    u64 local_records = 0, big_records = 0;   // of the last build: records sorted in LDS / through the big-group list
     bool debug_rounds = false;
     // query acceleration (sa_query.hpp): sorted packed keys K + bucket directory
     const u64* qkeys = nullptr;   // points into keys0/keys1 (build) or keys0 (load)
@@ -977,6 +981,7 @@ struct Builder {
         if (const char* e = getenv("SA_HIP_TEXT_PASS")) text_top_pass = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_NARROW_K")) narrow_k = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_TINY")) tiny_finisher = atoi(e) != 0;
+        if (const char* e = getenv("SA_HIP_LOCAL_ROUNDS")) local_rounds = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_DEBUG_ROUNDS")) debug_rounds = atoi(e) != 0;
         if (debug_rounds) { radix.debug_hook = &Builder::sort_debug_hook; radix.debug_ctx = this; }
         if ((rc = radix.init(cap, sort_block))) return rc;
@@ -1000,7 +1005,8 @@ struct Builder {
     }
     void destroy() {
         DevBuf* all[] = {&text, &keys0, &keys1, &vals0, &vals1, &flags, &counts, &small, &isa, &apos0, &apos1, &aidx,
-                         &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir, &dbg, &done, &pilot};
+                         &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir, &dbg, &done, &pilot,
+                         &gstart, &loc_tiles, &big_keys, &big_vals};
         for (DevBuf* b : all) b->release();
         radix.destroy();
         narrow.destroy();
@@ -1245,10 +1251,64 @@ struct Builder {
         return 0;
     }
 
+    // Sort of one round's records (keys = gid << gid_shift | low bits, ordered by gid already; values = suffix indices):
+    // groups are sorted where they lie, tile by tile in LDS (round_sort.hpp); the few groups that do not fit a tile go
+    // through the global sort as a compact list.  Falls back to the global sort of everything when more than half of
+    // the records sit in such groups (long repeats: a few huge groups).  Result in (k1, v1) or wherever the global sort
+    // leaves it.
+    int round_sort(u64* k0, u32* v0, u64* k1, u32* v1, u32 M, u32 G, int begin_bit, int end_bit, int gid_shift, u64** kres,
+                   u32** vres) {
+        int rc;
+        int top = (gid_shift < 64 - LOC_GID_BITS) ? gid_shift + LOC_GID_BITS : 64;
+        if (top > end_bit) top = end_bit;
+        // (an average group of more than half a tile: most records would take the big-group route anyway -- all-'a',
+        //  Fibonacci strings: no planning, no extra synchronisation)
+        if (!local_rounds || G == 0 || top <= begin_bit || (u64)M > (u64)G * (LOC_CAP / 2))
+            return radix_sort_pairs(radix, stream, k0, v0, k1, v1, M, begin_bit, end_bit, false, false, kres, vres);
+        const u32 ntiles = div_up(M, LOC_TILE);
+        if ((rc = gstart.ensure(((size_t)G + 2) * 4))) return rc;
+        if ((rc = loc_tiles.ensure((size_t)ntiles * sizeof(LocTile) + 64))) return rc;
+        u32* total_dev = reinterpret_cast<u32*>(small.as<u8>() + 3616);
+        hipLaunchKernelGGL(group_starts_kernel, dim3(stream_grid(M, 1024)), dim3(256), 0, stream, gid.as<u32>(), M, G, gstart.as<u32>());
+        hipLaunchKernelGGL(loc_plan_kernel, dim3(div_up(ntiles, 256)), dim3(256), 0, stream, gid.as<u32>(), gstart.as<u32>(), M, ntiles,
+                           loc_tiles.as<LocTile>());
+        hipLaunchKernelGGL(loc_scan_kernel, dim3(1), dim3(1024), 0, stream, loc_tiles.as<LocTile>(), ntiles, total_dev);
+        u32 big = 0;
+        SA_HIP_CHECK(hipMemcpyAsync(&big, total_dev, 4, hipMemcpyDeviceToHost, stream));
+        SA_HIP_CHECK(hipStreamSynchronize(stream));
+        if ((u64)big * 2 > M)
+            return radix_sort_pairs(radix, stream, k0, v0, k1, v1, M, begin_bit, end_bit, false, false, kres, vres);
+        LocSortArgs a;
+        a.keys_in = k0; a.vals_in = v0; a.keys_out = k1; a.vals_out = v1; a.tiles = loc_tiles.as<LocTile>();
+        a.begin_bit = begin_bit; a.gid_shift = gid_shift; a.top = top;
+        a.passes = (top - begin_bit + RADIX_BITS - 1) / RADIX_BITS;
+        hipLaunchKernelGGL(loc_sort_kernel, dim3(ntiles), dim3(LOC_BLOCK), 0, stream, a);
+        local_records += (u64)M - big;
+        if (big) {
+            big_records += big;
+            if ((rc = big_keys.ensure((size_t)big * 8))) return rc;
+            if ((rc = big_vals.ensure((size_t)big * 4))) return rc;
+            const u32 cg = ntiles < 2048u ? ntiles : 2048u;
+            hipLaunchKernelGGL(loc_big_copy_kernel, dim3(cg), dim3(256), 0, stream, (const LocTile*)loc_tiles.as<LocTile>(), ntiles, true,
+                               k0, v0, big_keys.as<u64>(), big_vals.as<u32>());
+            // (k0, v0) are free from here on: the partner buffers of the list's ping-pong
+            u64* rk; u32* rv;
+            if ((rc = radix_sort_pairs(radix, stream, big_keys.as<u64>(), big_vals.as<u32>(), k0, v0, big, begin_bit, end_bit, false,
+                                       false, &rk, &rv))) return rc;
+            hipLaunchKernelGGL(loc_big_copy_kernel, dim3(cg), dim3(256), 0, stream, (const LocTile*)loc_tiles.as<LocTile>(), ntiles, false,
+                               k1, v1, rk, rv);
+        }
+        SA_HIP_CHECK(hipGetLastError());
+        *kres = k1;
+        *vres = v1;
+        return 0;
+    }
+
     // The device build.  Text already resident in text.p[0..n_).
     int build(u64 n_, u32 L) {
         int rc;
         memset(&stats, 0, sizeof stats);
+        local_records = big_records = 0;
         radix.reset_stats();
         max_suffix_length = L;
         stats.n = n_;
@@ -1409,8 +1469,8 @@ struct Builder {
             // sort the active records; aidx is the value array
             SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
             const int end_bit = use_chunk ? 64 : (gb + rb);
-            if ((rc = radix_sort_pairs(radix, stream, rkeys0.as<u64>(), ridx0.as<u32>(), rkeys1.as<u64>(), ridx1.as<u32>(), M,
-                                       begin_bit, end_bit, false, false, &kres, &vres))) return rc;
+            if ((rc = round_sort(rkeys0.as<u64>(), ridx0.as<u32>(), rkeys1.as<u64>(), ridx1.as<u32>(), M, G, begin_bit, end_bit,
+                                 use_chunk ? (gb ? 64 - gb : 64) : rb, &kres, &vres))) return rc;
             // write back, new heads, counts
             if ((rc = flags_and_counts(kres, M, lf.as<u8>(), apos_cur, vres, tot))) return rc;
             if ((rc = check_device_status())) return rc;
