@@ -125,10 +125,15 @@ struct LocSortArgs {
     int passes;       // ceil((top - begin_bit) / 8)
 };
 
+// PACKED (the usual case: at most 52 key bits differ inside a tile): a record travels as ONE 64-bit word -- the
+// significant key bits above the record's 12-bit position in the tile -- so a pass moves 8 instead of 12 bytes per
+// record through LDS and the values are fetched once, at the end, from where they lie (36 KB of LDS: four workgroups
+// per CU instead of three).
+template <bool PACKED>
 __global__ __launch_bounds__(LOC_BLOCK) void loc_sort_kernel(LocSortArgs a) {
     constexpr int WAVES = LOC_BLOCK / WAVE;
     __shared__ u64 s_key[LOC_CAP];
-    __shared__ u32 s_val[LOC_CAP];
+    __shared__ u32 s_val[PACKED ? 1 : LOC_CAP];
     __shared__ u32 s_whist[WAVES * RADIX];
     __shared__ u32 s_wsum[WAVES];
     const LocTile lt = a.tiles[blockIdx.x];
@@ -140,19 +145,25 @@ __global__ __launch_bounds__(LOC_BLOCK) void loc_sort_kernel(LocSortArgs a) {
     const u32* vin = a.vals_in + lt.begin;
     // the tile's smallest group id comes off every key: what is left of it fits LOC_GID_BITS
     const u64 base = (a.gid_shift < 64) ? ((kin[0] >> a.gid_shift) << a.gid_shift) : 0ull;
+    const int first_bit = PACKED ? LOC_GID_BITS : a.begin_bit;               // lowest bit the passes look at
+    const int top = PACKED ? a.top - a.begin_bit + LOC_GID_BITS : a.top;      // one past the highest
 
     u64 key[LOC_ITEMS];
-    u32 val[LOC_ITEMS];
+    u32 val[PACKED ? 1 : LOC_ITEMS];
 #pragma unroll
     for (int j = 0; j < LOC_ITEMS; ++j) {
         const u32 p = woff + j * WAVE;
-        key[j] = (p < cnt) ? kin[p] - base : ~0ull;   // padding sorts last in every pass and stays behind the records (stable)
-        val[j] = (p < cnt) ? vin[p] : 0u;
+        // padding sorts last in every pass and stays behind the records (stable)
+        if (PACKED) key[j] = (p < cnt) ? ((((kin[p] - base) >> a.begin_bit) << LOC_GID_BITS) | (u64)p) : ~0ull;
+        else {
+            key[j] = (p < cnt) ? kin[p] - base : ~0ull;
+            val[j] = (p < cnt) ? vin[p] : 0u;
+        }
     }
     u32* wh = s_whist + wave * RADIX;
     for (int pass = 0; pass < a.passes; ++pass) {
-        const int shift = a.begin_bit + RADIX_BITS * pass;
-        const int bits = (a.top - shift) < RADIX_BITS ? (a.top - shift) : RADIX_BITS;
+        const int shift = first_bit + RADIX_BITS * pass;
+        const int bits = (top - shift) < RADIX_BITS ? (top - shift) : RADIX_BITS;
         const u32 mask = (1u << bits) - 1u;
         for (int i = tid; i < WAVES * RADIX; i += LOC_BLOCK) s_whist[i] = 0;
         __syncthreads();
@@ -188,14 +199,14 @@ __global__ __launch_bounds__(LOC_BLOCK) void loc_sort_kernel(LocSortArgs a) {
         for (int j = 0; j < LOC_ITEMS; ++j) {
             const u32 pos = wh[rd[j] >> 16] + (rd[j] & 0xFFFFu);
             s_key[pos] = key[j];
-            s_val[pos] = val[j];
+            if (!PACKED) s_val[pos] = val[j];
         }
         __syncthreads();
         if (pass + 1 < a.passes) {
 #pragma unroll
             for (int j = 0; j < LOC_ITEMS; ++j) {
                 key[j] = s_key[woff + j * WAVE];
-                val[j] = s_val[woff + j * WAVE];
+                if (!PACKED) val[j] = s_val[woff + j * WAVE];
             }
             __syncthreads();
         }
@@ -203,11 +214,18 @@ __global__ __launch_bounds__(LOC_BLOCK) void loc_sort_kernel(LocSortArgs a) {
     u64* kout = a.keys_out + lt.begin;
     u32* vout = a.vals_out + lt.begin;
     for (u32 p = tid; p < cnt; p += LOC_BLOCK) {
-        kout[p] = s_key[p] + base;
-        vout[p] = s_val[p];
+        const u64 k = s_key[p];
+        if (PACKED) {
+            kout[p] = ((k >> LOC_GID_BITS) << a.begin_bit) + base;
+            vout[p] = vin[(u32)k & (LOC_CAP - 1u)];   // the record's position in the tile before the sort
+        } else {
+            kout[p] = k + base;
+            vout[p] = s_val[p];
+        }
     }
 }
 
+static_assert(LOC_CAP == (1u << LOC_GID_BITS), "a position in the tile fits the bits the local group id frees");
 static_assert(LOC_BLOCK == RADIX, "loc_sort_kernel scans one digit per thread");
 
 }  // namespace sa

@@ -1282,7 +1282,8 @@ struct Builder {
         a.keys_in = k0; a.vals_in = v0; a.keys_out = k1; a.vals_out = v1; a.tiles = loc_tiles.as<LocTile>();
         a.begin_bit = begin_bit; a.gid_shift = gid_shift; a.top = top;
         a.passes = (top - begin_bit + RADIX_BITS - 1) / RADIX_BITS;
-        hipLaunchKernelGGL(loc_sort_kernel, dim3(ntiles), dim3(LOC_BLOCK), 0, stream, a);
+        if (top - begin_bit + LOC_GID_BITS <= 64) hipLaunchKernelGGL(loc_sort_kernel<true>, dim3(ntiles), dim3(LOC_BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL(loc_sort_kernel<false>, dim3(ntiles), dim3(LOC_BLOCK), 0, stream, a);
         local_records += (u64)M - big;
         if (big) {
             big_records += big;
