@@ -152,3 +152,39 @@ def test_narrow_record_sort_matches_plain_sort(gpu, oracle, monkeypatch):
     with gpu.DeviceIndex(t.size, 0) as idx:
         idx.build(t)
         assert np.array_equal(idx.sa_u32(), oracle.sais(t).astype(np.uint32))
+
+
+def test_rounds_sorted_in_lds_match_global_sort(gpu, oracle, monkeypatch):
+    """Refinement rounds are sorted group-wise in LDS (round_sort.hpp: tiles of whole groups, 12-bit local group ids,
+    packed and unpacked record form, groups too large for a tile through the global sort as a compact list).  Same
+    suffix array as with SA_HIP_LOCAL_ROUNDS=0 (every round through the global 8-pass sort), verified on the device:
+    word text (millions of small groups, later rounds with few groups: the unpacked form), names with a truncation depth,
+    a block repeated 12 times (doubling rounds, groups of 12), a text with one 60 000-character run (a group far larger
+    than a tile next to small ones), a skewed alphabet (dense active set, groups of every size)."""
+    from suffixarray_amd import synth
+    rng = np.random.default_rng(31)
+    words = synth.d2_words(6_000_000)
+    run = synth.d2_words(3_000_000).copy()
+    run[1_000_000:1_060_000] = ord("q")
+    skew = rng.choice(np.array([97, 98, 99, 100, 122], dtype=np.uint8), 3_000_000, p=[0.9, 0.04, 0.03, 0.02, 0.01])
+    blk = np.tile(rng.integers(97, 101, 200_000, dtype=np.uint8), 12)
+    runs = [("words", words, 0), ("words_L20", words, 20), ("run", run, 0), ("skew", skew, 0), ("blocks", blk, 0),
+            ("d2_300k", cases.small_texts()["d2_300k"], 0), ("repeat_block", cases.small_texts()["repeat_block"], 0)]
+    for name, t, L in runs:
+        got, stats = {}, {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SA_HIP_LOCAL_ROUNDS", mode)
+            with gpu.DeviceIndex(t.size, 0) as idx:
+                idx.build(t, L)
+                stats[mode] = idx.build_stats()
+                assert idx.verify() == 0, (name, mode, stats[mode])
+                got[mode] = idx.sa_u32().copy()
+        assert stats["1"]["rounds"] >= 1, (name, stats["1"])
+        assert np.array_equal(got["1"], got["0"]), (name, stats)
+        if name in ("words", "d2_300k", "repeat_block"):
+            assert np.array_equal(got["1"], oracle.sais(t).astype(np.uint32)), name
+        if name == "words_L20":
+            assert np.array_equal(got["1"], oracle.truncated_sa(t, 20)), name
+        # the global sort launches fewer passes when the rounds go through LDS
+        if name in ("words", "blocks"):
+            assert stats["1"]["radix_passes"] < stats["0"]["radix_passes"], (name, stats)
