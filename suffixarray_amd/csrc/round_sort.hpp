@@ -7,7 +7,7 @@
 //   * the list is cut into tiles of whole groups: tile t = the groups that START in [t*T, (t+1)*T)
 //     (a_t = start of the first group that starts at or after t*T, O(1) from gstart[gid]);
 //   * a tile of at most C = 4096 records is sorted by ONE workgroup entirely in LDS: keys and values are read
-//     once and written once (16 instead of 8 * 24 bytes of HBM traffic per record), and the group id shrinks to
+//     once and written once (24 instead of 8 * 24 bytes of HBM traffic per record), and the group id shrinks to
 //     the 12 bits that tell the groups of one tile apart (local gid = gid - gid of the tile's first record):
 //     ceil((low bits + 12) / 8) passes -- 6 for a chunk round of 7 five-bit characters -- of ballot-match
 //     ranking (wave_rank, stable) with the records held in registers between passes;
@@ -20,11 +20,16 @@
 
 namespace sa {
 
-constexpr int LOC_BLOCK = 256;
+// 256 threads x 16 records.  512 threads (tiles of 8192, 13-bit local ids, 72 KB of LDS: two workgroups per CU, fewer
+// groups through the big-group list) measured SLOWER on the same box: names 1e8 12.9 against 12.0 ms, words 14.9 against 13.95.
+#ifndef SA_LOC_BLOCK
+#define SA_LOC_BLOCK 256
+#endif
+constexpr int LOC_BLOCK = SA_LOC_BLOCK;          // 256 or 512 threads
 constexpr int LOC_ITEMS = 16;
-constexpr u32 LOC_CAP = LOC_BLOCK * LOC_ITEMS;   // 4096 records per workgroup
-constexpr u32 LOC_TILE = 3072;                   // nominal tile: groups of up to LOC_CAP - LOC_TILE + 1 records never overflow
-constexpr int LOC_GID_BITS = 12;                 // local group ids < LOC_CAP
+constexpr u32 LOC_CAP = LOC_BLOCK * LOC_ITEMS;   // 4096 (8192) records per workgroup
+constexpr u32 LOC_TILE = LOC_CAP - LOC_CAP / 4;  // nominal tile: groups of up to LOC_CAP / 4 + 1 records never overflow
+constexpr int LOC_GID_BITS = (LOC_BLOCK == 512) ? 13 : 12;   // local group ids < LOC_CAP
 
 // gstart[g] = first record of group g (gid is dense and ascending); gstart[G] = M
 __global__ __launch_bounds__(256) void group_starts_kernel(const u32* __restrict__ gid, u32 m_count, u32 groups,
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(LOC_BLOCK) void loc_sort_kernel(LocSortArgs a) {
     __shared__ u64 s_key[LOC_CAP];
     __shared__ u32 s_val[PACKED ? 1 : LOC_CAP];
     __shared__ u32 s_whist[WAVES * RADIX];
-    __shared__ u32 s_wsum[WAVES];
+    __shared__ u32 s_wsum[RADIX / WAVE];
     const LocTile lt = a.tiles[blockIdx.x];
     const u32 cnt = lt.local_end - lt.begin;   // <= LOC_CAP
     if (cnt == 0) return;
@@ -170,23 +175,25 @@ __global__ __launch_bounds__(LOC_BLOCK) void loc_sort_kernel(LocSortArgs a) {
         u32 rd[LOC_ITEMS];
         wave_rank<true>(key, shift, mask, woff, LOC_CAP, wh, rd);
         __syncthreads();
-        // digit counts of the tile -> per-wave exclusive offsets (LOC_BLOCK == RADIX: one digit per thread)
-        {
-            u32 c = 0;
+        // digit counts of the tile -> per-wave exclusive offsets (the first RADIX threads: one digit each)
+        u32 c = 0, incl = 0;
+        if (tid < RADIX) {
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) {
                 const u32 t = s_whist[w * RADIX + tid];
                 s_whist[w * RADIX + tid] = c;
                 c += t;
             }
-            u32 incl = c;
+            incl = c;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const u32 t = __shfl_up(incl, o);
                 if (lane >= o) incl += t;
             }
             if (lane == 63) s_wsum[wave] = incl;
-            __syncthreads();
+        }
+        __syncthreads();
+        if (tid < RADIX) {
             u32 excl = incl - c;
             for (int i = 0; i < wave; ++i) excl += s_wsum[i];
 #pragma unroll
@@ -226,6 +233,6 @@ __global__ __launch_bounds__(LOC_BLOCK) void loc_sort_kernel(LocSortArgs a) {
 }
 
 static_assert(LOC_CAP == (1u << LOC_GID_BITS), "a position in the tile fits the bits the local group id frees");
-static_assert(LOC_BLOCK == RADIX, "loc_sort_kernel scans one digit per thread");
+static_assert(LOC_BLOCK >= RADIX && LOC_BLOCK % WAVE == 0, "one digit per thread in the scan");
 
 }  // namespace sa
