@@ -28,7 +28,12 @@ namespace sa {
 constexpr int LOC_BLOCK = SA_LOC_BLOCK;          // 256 or 512 threads
 constexpr int LOC_ITEMS = 16;
 constexpr u32 LOC_CAP = LOC_BLOCK * LOC_ITEMS;   // 4096 (8192) records per workgroup
-constexpr u32 LOC_TILE = LOC_CAP - LOC_CAP / 4;  // nominal tile: groups of up to LOC_CAP / 4 + 1 records never overflow
+// nominal tile = 7/8 of the capacity: groups of up to LOC_CAP / 8 + 1 records never overflow; slack 1/2, 1/4, 1/8, 1/16, 1/32 of
+// the capacity measured (names 1e8): 12.46, 12.04, 11.74-11.92, 12.07, 12.20 ms -- padding lanes against overflowing groups
+#ifndef SA_LOC_SLACK_DIV
+#define SA_LOC_SLACK_DIV 8
+#endif
+constexpr u32 LOC_TILE = LOC_CAP - LOC_CAP / SA_LOC_SLACK_DIV;
 constexpr int LOC_GID_BITS = (LOC_BLOCK == 512) ? 13 : 12;   // local group ids < LOC_CAP
 
 // gstart[g] = first record of group g (gid is dense and ascending); gstart[G] = M
