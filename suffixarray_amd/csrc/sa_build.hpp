@@ -1256,15 +1256,20 @@ struct Builder {
     // through the global sort as a compact list.  Falls back to the global sort of everything when more than half of
     // the records sit in such groups (long repeats: a few huge groups).  Result in (k1, v1) or wherever the global sort
     // leaves it.
-    int round_sort(u64* k0, u32* v0, u64* k1, u32* v1, u32 M, u32 G, int begin_bit, int end_bit, int gid_shift, u64** kres,
-                   u32** vres) {
+    // vsrc: the values in list order (read only; the global sort works on a copy of them in v0).
+    int round_sort(u64* k0, const u32* vsrc, u32* v0, u64* k1, u32* v1, u32 M, u32 G, int begin_bit, int end_bit, int gid_shift,
+                   u64** kres, u32** vres) {
         int rc;
+        auto global_sort = [&]() -> int {
+            SA_HIP_CHECK(hipMemcpyAsync(v0, vsrc, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
+            return radix_sort_pairs(radix, stream, k0, v0, k1, v1, M, begin_bit, end_bit, false, false, kres, vres);
+        };
         int top = (gid_shift < 64 - LOC_GID_BITS) ? gid_shift + LOC_GID_BITS : 64;
         if (top > end_bit) top = end_bit;
         // (an average group of more than half a tile: most records would take the big-group route anyway -- all-'a',
         //  Fibonacci strings: no planning, no extra synchronisation)
         if (!local_rounds || G == 0 || top <= begin_bit || (u64)M > (u64)G * (LOC_CAP / 2))
-            return radix_sort_pairs(radix, stream, k0, v0, k1, v1, M, begin_bit, end_bit, false, false, kres, vres);
+            return global_sort();
         const u32 ntiles = div_up(M, LOC_TILE);
         if ((rc = gstart.ensure(((size_t)G + 2) * 4))) return rc;
         if ((rc = loc_tiles.ensure((size_t)ntiles * sizeof(LocTile) + 64))) return rc;
@@ -1277,9 +1282,9 @@ struct Builder {
         SA_HIP_CHECK(hipMemcpyAsync(&big, total_dev, 4, hipMemcpyDeviceToHost, stream));
         SA_HIP_CHECK(hipStreamSynchronize(stream));
         if ((u64)big * 2 > M)
-            return radix_sort_pairs(radix, stream, k0, v0, k1, v1, M, begin_bit, end_bit, false, false, kres, vres);
+            return global_sort();
         LocSortArgs a;
-        a.keys_in = k0; a.vals_in = v0; a.keys_out = k1; a.vals_out = v1; a.tiles = loc_tiles.as<LocTile>();
+        a.keys_in = k0; a.vals_in = vsrc; a.keys_out = k1; a.vals_out = v1; a.tiles = loc_tiles.as<LocTile>();
         a.begin_bit = begin_bit; a.gid_shift = gid_shift; a.top = top;
         a.passes = (top - begin_bit + RADIX_BITS - 1) / RADIX_BITS;
         if (top - begin_bit + LOC_GID_BITS <= 64) hipLaunchKernelGGL(loc_sort_kernel<true>, dim3(ntiles), dim3(LOC_BLOCK), 0, stream, a);
@@ -1291,7 +1296,7 @@ struct Builder {
             if ((rc = big_vals.ensure((size_t)big * 4))) return rc;
             const u32 cg = ntiles < 2048u ? ntiles : 2048u;
             hipLaunchKernelGGL(loc_big_copy_kernel, dim3(cg), dim3(256), 0, stream, (const LocTile*)loc_tiles.as<LocTile>(), ntiles, true,
-                               k0, v0, big_keys.as<u64>(), big_vals.as<u32>());
+                               k0, const_cast<u32*>(vsrc), big_keys.as<u64>(), big_vals.as<u32>());
             // (k0, v0) are free from here on: the partner buffers of the list's ping-pong
             u64* rk; u32* rv;
             if ((rc = radix_sort_pairs(radix, stream, big_keys.as<u64>(), big_vals.as<u32>(), k0, v0, big, begin_bit, end_bit, false,
@@ -1467,10 +1472,9 @@ struct Builder {
                 h_next = 2 * h;
                 ++stats.doubling_rounds;
             }
-            // sort the active records; aidx is the value array
-            SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
+            // sort the active records; aidx is the value array (read in place by the tile-local sort)
             const int end_bit = use_chunk ? 64 : (gb + rb);
-            if ((rc = round_sort(rkeys0.as<u64>(), ridx0.as<u32>(), rkeys1.as<u64>(), ridx1.as<u32>(), M, G, begin_bit, end_bit,
+            if ((rc = round_sort(rkeys0.as<u64>(), aidx.as<u32>(), ridx0.as<u32>(), rkeys1.as<u64>(), ridx1.as<u32>(), M, G, begin_bit, end_bit,
                                  use_chunk ? (gb ? 64 - gb : 64) : rb, &kres, &vres))) return rc;
             // write back, new heads, counts
             if ((rc = flags_and_counts(kres, M, lf.as<u8>(), apos_cur, vres, tot))) return rc;
