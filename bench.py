@@ -272,6 +272,13 @@ def main():
                                        "key array replace most of its probes, so the kernel moves far fewer real bytes and this figure can exceed the peak"},
             "gate": gate,
         }
+        if last.get("narrow_k") and last.get("text_top_pass") and last.get("rounds") == 0:
+            # the whole build with its own bytes / time: the sort passes as accounted above + per character
+            # byte histogram 1, top-digit histogram 1, bucket histogram 4, flags pass 4 + 1, compaction 1
+            other = 12.0
+            total_bytes = radix_bytes + other * N * steps
+            line["whole_build"] = {"bytes_per_char_model": total_bytes / (N * steps), "achieved": total_bytes / (build_ms / 1e3) / 1e9,
+                                   "unit": "GB/s", "frac": total_bytes / (build_ms / 1e3) / HBM_PEAK}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(text, q_buf, q_off, min(args.cpu_sample, N), min(Q, 1_000_000))
         print(json.dumps(line))
