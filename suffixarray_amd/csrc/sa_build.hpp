@@ -918,6 +918,7 @@ struct Builder {
     bool local_rounds = true;         // SA_HIP_LOCAL_ROUNDS: rounds sorted group-wise in LDS (round_sort.hpp)
     DevBuf gstart, loc_tiles, big_keys, big_vals;
     u64 local_records = 0, big_records = 0;   // of the last build: records sorted in LDS / through the big-group list
+    LocTile one_tile{};                       // source of an asynchronous copy (round_sort, lists of at most one tile)
     bool debug_rounds = false;
     // query acceleration (sa_query.hpp): sorted packed keys K + bucket directory
     const u64* qkeys = nullptr;   // points into keys0/keys1 (build) or keys0 (load)
@@ -1268,21 +1269,28 @@ struct Builder {
         if (top > end_bit) top = end_bit;
         // (an average group of more than half a tile: most records would take the big-group route anyway -- all-'a',
         //  Fibonacci strings: no planning, no extra synchronisation)
-        if (!local_rounds || G == 0 || top <= begin_bit || (u64)M > (u64)G * (LOC_CAP / 2))
+        if (!local_rounds || G == 0 || top <= begin_bit || (M > LOC_CAP && (u64)M > (u64)G * (LOC_CAP / 2)))
             return global_sort();
-        const u32 ntiles = div_up(M, LOC_TILE);
+        u32 ntiles = div_up(M, LOC_TILE);
         if ((rc = gstart.ensure(((size_t)G + 2) * 4))) return rc;
         if ((rc = loc_tiles.ensure((size_t)ntiles * sizeof(LocTile) + 64))) return rc;
         u32* total_dev = reinterpret_cast<u32*>(small.as<u8>() + 3616);
+        u32 big = 0;
+        if (M <= LOC_CAP) {
+            // the whole list fits one workgroup (the last rounds of a build): one tile, nothing to plan, no round trip
+            one_tile.begin = 0; one_tile.local_end = M; one_tile.end = M; one_tile.big_off = 0;
+            SA_HIP_CHECK(hipMemcpyAsync(loc_tiles.p, &one_tile, sizeof one_tile, hipMemcpyHostToDevice, stream));
+            ntiles = 1;
+        } else {
         hipLaunchKernelGGL(group_starts_kernel, dim3(stream_grid(M, 1024)), dim3(256), 0, stream, gid.as<u32>(), M, G, gstart.as<u32>());
         hipLaunchKernelGGL(loc_plan_kernel, dim3(div_up(ntiles, 256)), dim3(256), 0, stream, gid.as<u32>(), gstart.as<u32>(), M, ntiles,
                            loc_tiles.as<LocTile>());
         hipLaunchKernelGGL(loc_scan_kernel, dim3(1), dim3(1024), 0, stream, loc_tiles.as<LocTile>(), ntiles, total_dev);
-        u32 big = 0;
         SA_HIP_CHECK(hipMemcpyAsync(&big, total_dev, 4, hipMemcpyDeviceToHost, stream));
         SA_HIP_CHECK(hipStreamSynchronize(stream));
         if ((u64)big * 2 > M)
             return global_sort();
+        }
         LocSortArgs a;
         a.keys_in = k0; a.vals_in = vsrc; a.keys_out = k1; a.vals_out = v1; a.tiles = loc_tiles.as<LocTile>();
         a.begin_bit = begin_bit; a.gid_shift = gid_shift; a.top = top;
