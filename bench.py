@@ -4,17 +4,26 @@ SA build chars/s (N = 1e9) + batched queries/s (Q = 1e6) on one MI355X, % of HBM
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--chars CHARS] [--queries QUERIES]
 
-A "step" = one device build of the suffix array of the N-char synthetic text D1 (uniform27,
-SURVEY.md 8d; text resident in HBM before the timed region) + one batch of Q 16-byte queries
-(50 % text windows, 50 % random; patterns resident in HBM).  N > 1 GPUs (launched by
-torch.distributed.run, one rank per GPU): construction does not shard ("replicas only", every
-rank builds its own replica); the query batch is weak-scaled (Q per GPU) and the results are
-all-gathered over RCCL; the one-time RCCL broadcast of (text, SA) is timed separately.
+N = 1 (BASELINE config 3: "1 GB text (libsais64 path), 64-bit SA build + 1M batched 16-byte queries"):
+a "step" = one device build of the suffix array of the N-char synthetic text D1 (uniform27; text
+resident in HBM before the timed region) + the widening pass that leaves the result in libsais64 layout
+(int64[N], device resident) + one batch of Q 16-byte queries (50 % text windows, 50 % random; patterns
+resident in HBM).  `value` = N / (build + widen time): every byte config 3 names is inside it.
+
+N > 1 (BASELINE config 4: "1 GB text, 10M-query batch sharded across 8 GPUs, SA replicated via RCCL, hits
+gathered"; launched by torch.distributed.run, one rank per GPU): construction stays single-GPU -- rank 0 builds
+ONCE, text + SA reach the other GPUs by one RCCL broadcast per tensor (timed, `broadcast_ms`), every rank adopts
+the replica; a "step" = ONE global batch of --queries-global patterns (the same on every rank) split into
+contiguous slices, searched with no data-path collective, 8-byte ranges all-gathered (device resident).
+`value` = global queries/s (strong scaling); the build's chars/s is reported un-multiplied beside it.
 Prints ONE JSON line on rank 0.
 """
+import os
+
+os.environ.setdefault("OMP_DYNAMIC", "false")   # libsais turns its parallel regions off when omp_get_dynamic() (libsais.c:744)
+
 import argparse
 import json
-import os
 import sys
 import time
 
@@ -48,52 +57,97 @@ PASS_KERNELS = ["radix_onesweep_kernel<512, 0, false>", "radix_onesweep_kernel<5
                 "seg_onesweep_kernel<512, 24, false, true>", "seg_onesweep_kernel<512, 24, true, true>"]   # sa_hip_build_stats.pass_*
 
 
-def pmc_traffic(n, kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc run
-    (profiles/pmc_onesweep.json; PMC passes cannot run inside this process).  Only reported for
-    the workload and the kernel it was measured on."""
+def committed_pmc(name, n, kernel):
+    """HBM bytes from a committed rocprofv3 --pmc run (profiles/<name>; PMC passes cannot run inside this
+    process).  Only reported for the workload and the kernel it was measured on."""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "pmc_onesweep.json")))
+        j = json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return None
-    if n != 1_000_000_000 or j.get("kernel") != kernel:
+    if n != j.get("n_chars", 1_000_000_000) or j.get("kernel") != kernel:
         return None
-    return j["traffic_bytes_per_launch"]
+    return j
 
 
-def cpu_baseline(text, q_buf, q_off, sample_n, sample_q):
-    """Reference libsais64_omp (oracle/_ref, compiled from the reference's own sources) on a
-    bounded prefix of the same text, all host cores; falls back to the oracle port."""
+def cpu_baseline(text, q_buf, q_off, gpu_sa64, one_thread_n):
+    """The reference's libsais64_omp (oracle/_ref, compiled from the reference's own sources) on the SAME text at
+    full size, all usable host cores, best of two runs; the 1-thread libsais figure (the configuration the
+    reference's Makefile builds, Makefile:2-5) on a prefix; the oracle's OpenMP restatement of
+    get_substring_positions over the same batch.  Also returns whether the GPU's int64 suffix array equals
+    the reference's output (bit-exact at full size).  Falls back to the oracle port where oracle/_ref is absent."""
     from oracle.oracle import Oracle, Ref
-    t = np.ascontiguousarray(text[:sample_n])
     cores = usable_cpus()
     threads = int(os.environ.get("OMP_NUM_THREADS", cores))
-    os.environ.setdefault("OMP_DYNAMIC", "false")
     out = {}
     orc = Oracle()
+    n = text.size
+    equal = None
     if Ref.available():
         ref = Ref()
-        sa64 = np.zeros(t.size, dtype=np.int64)  # first-touched
-        t0 = time.perf_counter()
-        rc = ref.libsais64_into(t, sa64, threads)
-        dt = time.perf_counter() - t0
-        assert rc == 0
-        out.update(kind="reference", value=t.size / dt, unit="chars/s", cores=threads,
-                   sample=f"libsais64_omp(threads={threads}; {cores} cores visible, {os.cpu_count()} in the machine) on the first {t.size:,} chars of the same text, 1 run: {dt:.2f} s")
+        sa64 = np.zeros(n, dtype=np.int64)   # first-touched
+        runs = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            rc = ref.libsais64_into(text, sa64, threads)
+            runs.append(time.perf_counter() - t0)
+            assert rc == 0
+            if runs[-1] > 40.0:
+                break
+        dt = min(runs)
+        out.update(kind="reference", value=n / dt, unit="chars/s", cores=threads,
+                   sample=f"libsais64_omp(threads={threads}, OMP_DYNAMIC=false; {cores} cores usable, {os.cpu_count()} in the machine) "
+                          f"on the whole text, n = {n:,}, runs: {', '.join('%.2f s' % r for r in runs)} (best)")
+        if gpu_sa64 is not None:
+            equal = bool(np.array_equal(gpu_sa64, sa64))
         sa = sa64.astype(np.uint32)
-    else:
+        del sa64
+        m1 = min(one_thread_n, n)
+        t1 = np.ascontiguousarray(text[:m1])
+        s1 = np.zeros(m1, dtype=np.int32)
         t0 = time.perf_counter()
-        sa = orc.sais(t).astype(np.uint32)
+        rc = ref.lib.libsais(t1.ctypes.data, s1.ctypes.data, m1, 0, None)
+        d1 = time.perf_counter() - t0
+        assert rc == 0
+        out["one_thread"] = {"value": m1 / d1, "unit": "chars/s", "cores": 1,
+                             "sample": f"libsais (1 thread, the reference Makefile's configuration) on the first {m1:,} chars: {d1:.2f} s"}
+        del s1
+    else:
+        m1 = min(one_thread_n, n)
+        t1 = np.ascontiguousarray(text[:m1])
+        t0 = time.perf_counter()
+        sa = orc.sais(t1).astype(np.uint32)
         dt = time.perf_counter() - t0
-        out.update(kind="port", value=t.size / dt, unit="chars/s", cores=1,
-                   sample=f"oracle SA-IS port on the first {t.size:,} chars, 1 run: {dt:.2f} s")
+        out.update(kind="port", value=m1 / dt, unit="chars/s", cores=1,
+                   sample=f"oracle SA-IS port on the first {m1:,} chars, 1 run: {dt:.2f} s")
+        text = t1
     # query baseline: oracle restatement of get_substring_positions, OpenMP over the batch
-    nq = min(sample_q, q_off.size - 1)
+    nq = q_off.size - 1
     t0 = time.perf_counter()
-    orc.query_batch(t, sa, 0xFFFFFFFF, (q_buf[:int(q_off[nq])], q_off[:nq + 1]), threads=threads)
+    orc.query_batch(text, sa, 0xFFFFFFFF, (q_buf, q_off), threads=threads)
     dq = time.perf_counter() - t0
     out["queries_per_s"] = nq / dq
-    out["query_sample"] = f"{nq:,} of the same 16-byte patterns over the sample SA, {orc.threads_used} threads: {dq:.2f} s"
+    out["query_sample"] = f"{nq:,} of the same 16-byte patterns over the SA of the {text.size:,}-char text, {orc.threads_used} threads: {dq:.2f} s"
+    return out, equal
+
+
+def secondary_builds(_capi, synth, device):
+    """Non-headline inputs at N = 1e8, driver-visible: config 2 (D1, 32-bit SA) and D2 words (refinement rounds).
+    Device build time (HIP events), best of 3 after one warm-up; verified on the device."""
+    out = {}
+    n = 100_000_000
+    for name, gen in (("config2_d1_1e8", lambda: synth.d1_uniform27(n)), ("d2_words_1e8", lambda: synth.d2_words(n))):
+        text = gen()
+        with _capi.DeviceIndex(n, device) as idx:
+            idx.build(text)
+            tdev = idx.text_dev
+            ms = []
+            for _ in range(3):
+                idx.build_device(tdev, n, 0)
+                ms.append(idx.build_stats()["total_ms"])
+            st = idx.build_stats()
+            out[name] = {"n_chars": n, "build_ms": min(ms), "chars_per_s": n / (min(ms) / 1e3), "verify_violations": idx.verify(),
+                         "initial_chars": st["initial_chars"], "rounds": st["rounds"], "active_total": st["active_total"]}
+        del text
     return out
 
 
@@ -103,18 +157,19 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--chars", "--n", dest="n", type=int, default=1_000_000_000)
-    ap.add_argument("--queries", "--q", dest="q", type=int, default=1_000_000)
+    ap.add_argument("--queries", "--q", dest="q", type=int, default=1_000_000, help="batch size of the 1-GPU step")
+    ap.add_argument("--queries-global", type=int, default=10_000_000, help="global batch of the N > 1 step (config 4)")
     ap.add_argument("--pattern-len", type=int, default=16)
-    ap.add_argument("--cpu-sample", type=int, default=100_000_000)
+    ap.add_argument("--cpu-one-thread-chars", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--exercise-dist", action="store_true",
-                    help="run the multi-GPU code paths (RCCL init, result all-gather, index broadcast) even at world size 1")
+                    help="run the multi-GPU path (RCCL init, index broadcast, sharded batch, all-gather) at world size 1")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from suffixarray_amd import _capi, synth
-    from suffixarray_amd.distributed import broadcast_index
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -123,168 +178,263 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or (args.exercise_dist and "RANK" in os.environ)
-    if use_dist:
+    if world > 1 or args.exercise_dist:
+        if "RANK" not in os.environ:   # --exercise-dist started by hand
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29511"))
         dist.init_process_group("nccl", device_id=dev)
+        line = run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev)
+        if rank == 0:
+            print(json.dumps(line))
+        dist.destroy_process_group()
+        return
+    print(json.dumps(run_single(args, torch, _capi, synth, dev, local_rank)))
 
+
+def run_single(args, torch, _capi, synth, dev, device):
     N, Q, m = args.n, args.q, args.pattern_len
-    text = synth.d1_uniform27(N)                     # same text on every rank
-    q_buf, q_off = synth.query_batch(text, Q, m, seed=rank)  # each rank's own slice of the global batch
+    text = synth.d1_uniform27(N)
+    q_buf, q_off = synth.query_batch(text, Q, m, seed=0)
 
-    idx = _capi.DeviceIndex(N, local_rank)
+    idx = _capi.DeviceIndex(N, device)
     idx.build(text)                                  # uploads the text into the index's HBM buffer
     text_dev = idx.text_dev
     pat_t = torch.from_numpy(np.concatenate([q_buf, np.zeros(64, np.uint8)])).to(dev)
     off_t = torch.from_numpy(q_off.view(np.int64)).to(dev)
     out_t = torch.zeros(2 * Q, dtype=torch.int32, device=dev)
-
-    gathered = torch.empty(world * 2 * Q, dtype=torch.int32, device=dev) if use_dist else None
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+    sa64_t = torch.empty(N, dtype=torch.int64, device=dev)    # libsais64 layout, device resident
 
     def step():
         idx.build_device(text_dev, N, 0)
+        idx.widen_device(sa64_t.data_ptr())
         idx.query_batch_device(pat_t.data_ptr(), off_t.data_ptr(), Q, out_t.data_ptr())
         idx.sync()
-        if use_dist:   # hits gathered on every rank (8 bytes per query over RCCL)
-            dist.all_gather_into_tensor(gathered, out_t)
 
     for _ in range(args.warmup):
         step()
-    barrier()
-    build_ms, radix_ms, radix_launches, radix_bytes, query_ms = 0.0, 0.0, 0, 0, 0.0
+    torch.cuda.synchronize()
+    build_ms, widen_ms, radix_ms, radix_launches, radix_bytes, query_ms = 0.0, 0.0, 0.0, 0, 0, 0.0
     kind_ms, kind_bytes, kind_launches = [0.0] * 4, [0] * 4, [0] * 4
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         st = idx.build_stats()
         build_ms += st["total_ms"]
+        widen_ms += st["widen_ms"]
         radix_ms += st["radix_ms"]
         radix_launches += st["radix_passes"]
         radix_bytes += st["radix_bytes"]
         for k in range(4):
             kind_ms[k] += st["pass_ms"][k]; kind_bytes[k] += st["pass_bytes"][k]; kind_launches[k] += st["pass_launches"][k]
         query_ms += idx.query_stats()["kernel_ms"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    last = idx.build_stats()
+    steps = args.steps
+
+    # correctness gates, outside the timed region: on-device sufcheck of the last step's SA (the SA is unique:
+    # verified == bit-exact), and -- with the CPU baseline -- equality with the reference's libsais64 output
+    res = out_t.cpu().numpy().view(np.uint32).reshape(-1, 2)
+    hits = ((res[:, 1].astype(np.int64) - res[:, 0].astype(np.int64) + 1) & 0xFFFFFFFF) > 0
+    hits &= res[:, 0] != 0xFFFFFFFF
+    violations = idx.verify()
+    gate = {"verify_violations": violations, "query_hit_rate": float(hits.mean())}
+
+    total_ms = build_ms + widen_ms
+    chars_per_s = N * steps / (total_ms / 1e3)
+    queries_per_s = Q * steps / (query_ms / 1e3)
+    if last.get("text_top_pass"):
+        PASS_KERNELS[1] = "text_top_pass_kernel<512>"
+    # dominant kernel = the sort-pass kernel with the largest share of the timed region
+    dom = max(range(4), key=lambda k: kind_ms[k])
+    pass_ms = kind_ms[dom] / max(kind_launches[dom], 1)
+    bytes_per_launch = kind_bytes[dom] / max(kind_launches[dom], 1)
+    achieved = kind_bytes[dom] / (kind_ms[dom] / 1e3) if kind_ms[dom] > 0 else 0.0
+    all_achieved = radix_bytes / (radix_ms / 1e3) if radix_ms > 0 else 0.0
+    bq = 2 * int(np.ceil(np.log2(max(N, 2)))) * (4 + m)              # reference bytes per query
+    q_model = Q * steps * bq / (query_ms / 1e3) if query_ms > 0 else 0.0
+    pmc_sort = committed_pmc("pmc_onesweep.json", N, PASS_KERNELS[dom])
+    qk = "query_kernel<true>" if last.get("narrow_k") else "query_kernel<false>"
+    pmc_q = committed_pmc("pmc_query.json", N, qk)
+    rq = {"bound": "hbm", "kernel": qk, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+          "reference_model": {"bytes_per_query": bq, "achieved": q_model / 1e9,
+                              "note": "bytes of the REFERENCE algorithm per query (SURVEY 8d: 2*ceil(log2 N)*(4+m)); the directory and the key "
+                                      "array replace most of its probes, so this is not what the kernel moves"}}
+    if pmc_q and pmc_q.get("queries") == Q:
+        # measured HBM bytes of one batch (rocprofv3 --pmc, profiles/pmc_query.json) over THIS run's kernel time
+        tq = pmc_q["traffic_bytes_per_launch"]
+        rq.update(traffic=tq, bytes_per_query=tq / Q, achieved=tq / (query_ms / steps / 1e3) / 1e9,
+                  frac=tq / (query_ms / steps / 1e3) / HBM_PEAK,
+                  traffic_note="FETCH_SIZE x2 + WRITE_SIZE of one 1M-query launch, profiles/pmc_query.json")
+    else:
+        rq.update(traffic=None, achieved=None, frac=None)
+    line = {
+        "metric": "sa_build_chars_per_s",
+        "value": chars_per_s,
+        "unit": "chars/s",
+        "n_gpus": 1,
+        "steps": steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt * 1e3 / steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": ("u8 text / u32 narrow keys / u32 suffix indices / i64 output" if last.get("narrow_k")
+                  else "u8 text / u64 keys / u32 suffix indices / i64 output"),
+        "data": "synthetic",
+        "config": {"workload": f"config 3: D1 uniform27 text N={N:,} (libsais64 path), 64-bit SA build (32-bit device build + widening pass, "
+                               f"int64[N] device resident) + {Q:,} batched {m}-byte queries, 1 GPU",
+                   "n_chars": N, "queries": Q, "pattern_len": m, "parallelism": "single GPU"},
+        "build_ms": total_ms / steps,
+        "build_ms_u32": build_ms / steps,
+        "widen_ms": widen_ms / steps,
+        "chars_per_s_u32": N * steps / (build_ms / 1e3),
+        "queries_per_s": queries_per_s,
+        "query_ms": query_ms / steps,
+        "build_stats": {k: last[k] for k in ("sigma", "bits_per_symbol", "initial_chars", "rounds", "chunk_rounds",
+                                             "doubling_rounds", "final_depth", "radix_passes", "active_total", "narrow_k")},
+        "roofline": {"bound": "hbm", "kernel": PASS_KERNELS[dom], "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                     "traffic": pmc_sort["traffic_bytes_per_launch"] if pmc_sort else None,
+                     "traffic_note": "bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE on this workload, profiles/pmc_onesweep.json",
+                     "launches": kind_launches[dom], "avg_launch_ms": pass_ms, "bytes_per_launch": bytes_per_launch},
+        "sort_passes": {"achieved": all_achieved / 1e9, "unit": "GB/s", "frac": all_achieved / HBM_PEAK, "launches": radix_launches,
+                        "by_kernel": {PASS_KERNELS[k]: {"launches": kind_launches[k], "avg_launch_ms": kind_ms[k] / kind_launches[k],
+                                                        "bytes_per_launch": kind_bytes[k] / kind_launches[k],
+                                                        "achieved": kind_bytes[k] / kind_ms[k] / 1e6}
+                                      for k in range(4) if kind_launches[k]}},
+        "widen": {"bytes_per_launch": 12.0 * N, "avg_launch_ms": widen_ms / steps,
+                  "achieved": 12.0 * N * steps / (widen_ms / 1e3) / 1e9 if widen_ms > 0 else None, "unit": "GB/s"},
+        "roofline_query": rq,
+        "gate": gate,
+    }
+    if last.get("narrow_k") and last.get("text_top_pass") and last.get("rounds") == 0:
+        # the whole build with its own bytes / time: the sort passes as accounted above + per character
+        # byte histogram 1, top-digit histogram 1, bucket histogram 4, flags pass 4 + 1, compaction 1, widen 12
+        other = 12.0 + 12.0
+        total_bytes = radix_bytes + other * N * steps
+        line["whole_build"] = {"bytes_per_char_model": total_bytes / (N * steps), "achieved": total_bytes / (total_ms / 1e3) / 1e9,
+                               "unit": "GB/s", "frac": total_bytes / (total_ms / 1e3) / HBM_PEAK}
+    if not args.no_cpu_baseline:
+        gpu_sa64 = sa64_t.cpu().numpy()
+        del sa64_t
+        base, equal = cpu_baseline(text, q_buf, q_off, gpu_sa64, args.cpu_one_thread_chars)
+        del gpu_sa64
+        line["cpu_baseline"] = base
+        if equal is not None:
+            gate["sa64_equals_reference_libsais64"] = equal
+    gate["ok"] = bool(violations == 0 and gate.get("sa64_equals_reference_libsais64", True))
+    idx.close()
+    del text
+    if not args.no_secondary:
+        torch.cuda.empty_cache()
+        line["secondary"] = secondary_builds(_capi, synth, device)
+    return line
+
+
+def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
+    """BASELINE config 4 (see the module docstring)."""
+    from suffixarray_amd.distributed import ShardedBatch, broadcast_index, device_view, shard_bounds
+    N, Qg, m = args.n, args.queries_global, args.pattern_len
+    text = synth.d1_uniform27(N)                     # the same text on every rank: rank 0 indexes it, all draw patterns from it
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    # construction: rank 0 only, once
+    idx = _capi.DeviceIndex(N, local_rank)
+    build_ms = None
+    if rank == 0:
+        idx.build(text)
+        bms = []
+        for _ in range(max(1, args.warmup) + 2):
+            idx.build_device(idx.text_dev, N, 0)
+            bms.append(idx.build_stats()["total_ms"])
+        build_ms = min(bms[1:]) if len(bms) > 1 else bms[0]
+        tx_t = device_view(idx.text_dev, N, torch.uint8, dev)       # the index's own buffers: no staging copy
+        sa_t = device_view(idx.sa_dev, N, torch.int32, dev)
+    else:
+        tx_t = torch.empty(N, dtype=torch.uint8, device=dev)
+        sa_t = torch.empty(N, dtype=torch.int32, device=dev)
+    # replication: one RCCL broadcast per tensor
+    barrier()
+    b0 = time.perf_counter()
+    broadcast_index(tx_t, sa_t, src=0)
+    barrier()
+    bcast_ms = (time.perf_counter() - b0) * 1e3
+    if rank != 0:
+        t0 = time.perf_counter()
+        idx.load_device(tx_t.data_ptr(), sa_t.data_ptr(), N, 0)    # adopts the replica: key array + directory, no construction
+        adopt_ms = (time.perf_counter() - t0) * 1e3
+        del tx_t, sa_t
+    else:
+        adopt_ms = 0.0
+
+    # ONE global batch, the same on every rank; this rank's slice goes to its GPU
+    lo, hi = shard_bounds(Qg, world, rank)
+    q_buf, q_off = synth.query_batch(text, Qg, m, seed=0, lo=lo, hi=hi)
+    batch = ShardedBatch(q_buf, q_off, Qg, world, rank, dev)
+
+    def search(pat_t, off_t, q_local, out_t):
+        idx.query_batch_device(pat_t.data_ptr(), off_t.data_ptr(), q_local, out_t.data_ptr())
+        idx.sync()   # the index has its own stream; the gather runs on torch's
+
+    for _ in range(args.warmup):
+        batch.step(search)
+    barrier()
+    kern_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.step(search)
+        kern_ms += idx.query_stats()["kernel_ms"]
     barrier()
     dt = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([dt, build_ms, query_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt, build_ms_max, query_ms_max = tmax.tolist()
-    else:
-        build_ms_max, query_ms_max = build_ms, query_ms
-    last = idx.build_stats()
+    tmax = torch.tensor([dt, kern_ms, adopt_ms], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt, kern_ms_max, adopt_ms_max = tmax.tolist()
 
-    # one-time replication cost (north_star): RCCL broadcast of text + SA from rank 0
-    # The north-star replication path, outside the timed steps: rank 0's index (text + SA) reaches the
-    # other GPUs by one RCCL broadcast per tensor, every rank adopts the copy (sa_hip_index_load_device)
-    # and answers its slice of the batch from it; the ranges must equal those of its own build.
-    bcast_ms, replica_ok = None, None
-    if use_dist:
-        if rank == 0:
-            tx_t = torch.from_numpy(text).to(dev)
-            sa_t = torch.from_numpy(idx.sa_u32().view(np.int32)).to(dev)
-        else:
-            tx_t = torch.empty(N, dtype=torch.uint8, device=dev)
-            sa_t = torch.empty(N, dtype=torch.int32, device=dev)
-        barrier()
-        b0 = time.perf_counter()
-        broadcast_index(tx_t, sa_t, src=0)
-        barrier()
-        bcast_ms = (time.perf_counter() - b0) * 1e3
-        own = out_t.clone()
-        rep = _capi.DeviceIndex(N, local_rank)
-        rep.load_device(tx_t.data_ptr(), sa_t.data_ptr(), N, 0)
-        rep.query_batch_device(pat_t.data_ptr(), off_t.data_ptr(), Q, out_t.data_ptr())
-        rep.sync()
-        ok_t = torch.tensor([1 if torch.equal(own, out_t) else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
-        replica_ok = bool(ok_t.item())
-        rep.close()
-        del sa_t, tx_t
-
-    # correctness gate inside the bench: the SA of the last step is a suffix array (spot checks)
+    # gate: the gathered table (every rank holds it) equals what rank 0's own index answers for the whole batch
     gate = None
+    got = batch.results()
     if rank == 0:
-        res = out_t.cpu().numpy().view(np.uint32).reshape(-1, 2)
-        hits = ((res[:, 1].astype(np.int64) - res[:, 0].astype(np.int64) + 1) & 0xFFFFFFFF) > 0
-        hits &= res[:, 0] != 0xFFFFFFFF
-        probe = idx.sa_range(0, min(N, 1 << 16)).astype(np.int64)
-        ok = True
-        for a, b in zip(probe[:-1:97], probe[1::97]):
-            ok &= bytes(text[a:a + 64]) <= bytes(text[b:b + 64])
-        gate = {"sorted_probe_ok": bool(ok), "query_hit_rate": float(hits.mean())}
-
+        fb, fo = synth.query_batch(text, Qg, m, seed=0)
+        exp = idx.query_batch((fb, fo))
+        same = bool(np.array_equal(got["first"], exp["first"]) and np.array_equal(got["second"], exp["second"]))
+        hits = (((got["second"].astype(np.int64) - got["first"].astype(np.int64) + 1) & 0xFFFFFFFF) > 0) & (got["first"] != 0xFFFFFFFF)
+        gate = {"gathered_equals_single_gpu": same, "verify_violations": idx.verify(), "query_hit_rate": float(hits.mean())}
+        gate["ok"] = bool(same and gate["verify_violations"] == 0)
+    steps = args.steps
+    line = None
     if rank == 0:
-        steps = args.steps
-        chars_per_s = world * N * steps / (build_ms_max / 1e3)          # replicas: every rank builds N chars
-        queries_per_s = world * Q * steps / (query_ms_max / 1e3)
-        if last.get("text_top_pass"):
-            PASS_KERNELS[1] = "text_top_pass_kernel<512>"
-        # dominant kernel = the sort-pass kernel with the largest share of the timed region
-        dom = max(range(4), key=lambda k: kind_ms[k])
-        pass_ms = kind_ms[dom] / max(kind_launches[dom], 1)
-        bytes_per_launch = kind_bytes[dom] / max(kind_launches[dom], 1)
-        achieved = kind_bytes[dom] / (kind_ms[dom] / 1e3) if kind_ms[dom] > 0 else 0.0
-        all_achieved = radix_bytes / (radix_ms / 1e3) if radix_ms > 0 else 0.0
-        bq = 2 * int(np.ceil(np.log2(max(N, 2)))) * (4 + m)              # reference bytes per query
-        q_achieved = Q * steps * bq / (query_ms / 1e3) if query_ms > 0 else 0.0
         line = {
-            "metric": "sa_build_chars_per_s",
-            "value": chars_per_s,
-            "unit": "chars/s",
+            "metric": "batched_queries_per_s",
+            "value": Qg * steps / dt,
+            "unit": "queries/s",
             "n_gpus": world,
             "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
-            "dtype": ("u8 text / u32 narrow keys / u32 suffix indices" if last.get("narrow_k")
-                      else "u8 text / u64 keys / u32 suffix indices"),
+            "dtype": "u8 text / u32 suffix indices / u32 range pairs",
             "data": "synthetic",
-            "config": {"workload": f"D1 uniform27 text N={N:,} (32-bit device build, libsais64-compatible 64-bit output by widening kernel) + {Q:,} batched {m}-byte queries per GPU",
-                       "n_chars": N, "queries_per_gpu": Q, "pattern_len": m,
-                       "parallelism": "replicas (build) + sharded query batch" if world > 1 else "single GPU"},
-            "build_ms": build_ms_max / steps,
-            "queries_per_s": queries_per_s,
-            "query_ms": query_ms_max / steps,
+            "config": {"workload": f"config 4: D1 uniform27 text N={N:,}, ONE batch of {Qg:,} {m}-byte queries sharded over {world} GPU(s), "
+                                   "SA built on rank 0 and replicated by RCCL broadcast, ranges all-gathered",
+                       "n_chars": N, "queries_global": Qg, "pattern_len": m,
+                       "parallelism": f"replicated index, query batch sharded x{world} (no data-path collective; all_gather_into_tensor of 8-byte ranges)"},
+            "search_kernel_ms_max_rank": kern_ms_max / steps,
+            "search_only_queries_per_s": Qg * steps / (kern_ms_max / 1e3) if kern_ms_max > 0 else None,
+            "build_ms": build_ms,
+            "build_chars_per_s": N / (build_ms / 1e3),
             "broadcast_ms": bcast_ms,
-            "replica_query_ok": replica_ok,
-            "build_stats": {k: last[k] for k in ("sigma", "bits_per_symbol", "initial_chars", "rounds", "chunk_rounds",
-                                                 "doubling_rounds", "final_depth", "radix_passes", "active_total", "narrow_k")},
-            "roofline": {"bound": "hbm", "kernel": PASS_KERNELS[dom], "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                         "traffic": pmc_traffic(N, PASS_KERNELS[dom]),
-                         "traffic_note": "bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE on this workload, profiles/pmc_onesweep.json",
-                         "launches": kind_launches[dom], "avg_launch_ms": pass_ms, "bytes_per_launch": bytes_per_launch},
-            "sort_passes": {"achieved": all_achieved / 1e9, "unit": "GB/s", "frac": all_achieved / HBM_PEAK, "launches": radix_launches,
-                            "by_kernel": {PASS_KERNELS[k]: {"launches": kind_launches[k], "avg_launch_ms": kind_ms[k] / kind_launches[k],
-                                                            "bytes_per_launch": kind_bytes[k] / kind_launches[k],
-                                                            "achieved": kind_bytes[k] / kind_ms[k] / 1e6}
-                                          for k in range(4) if kind_launches[k]}},
-            "roofline_query": {"bound": "hbm", "kernel": "query_kernel<true>" if last.get("narrow_k") else "query_kernel<false>", "achieved": q_achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                               "unit": "GB/s", "frac": q_achieved / HBM_PEAK, "bytes_per_query_model": bq,
-                               "note": "bytes of the REFERENCE algorithm per query (SURVEY 8d: 2*ceil(log2 N)*(4+m)); the directory and the "
-                                       "key array replace most of its probes, so the kernel moves far fewer real bytes and this figure can exceed the peak"},
+            "broadcast_bytes": 5 * N,
+            "broadcast_gbps": 5 * N / (bcast_ms / 1e3) / 1e9,
+            "adopt_ms_max_rank": adopt_ms_max,
             "gate": gate,
         }
-        if last.get("narrow_k") and last.get("text_top_pass") and last.get("rounds") == 0:
-            # the whole build with its own bytes / time: the sort passes as accounted above + per character
-            # byte histogram 1, top-digit histogram 1, bucket histogram 4, flags pass 4 + 1, compaction 1
-            other = 12.0
-            total_bytes = radix_bytes + other * N * steps
-            line["whole_build"] = {"bytes_per_char_model": total_bytes / (N * steps), "achieved": total_bytes / (build_ms / 1e3) / 1e9,
-                                   "unit": "GB/s", "frac": total_bytes / (build_ms / 1e3) / HBM_PEAK}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(text, q_buf, q_off, min(args.cpu_sample, N), min(Q, 1_000_000))
-        print(json.dumps(line))
     idx.close()
-    if use_dist:
-        dist.destroy_process_group()
+    return line
 
 
 if __name__ == "__main__":

@@ -99,7 +99,8 @@ int sa_hip_index_build(sa_hip_index* idx, const uint8_t* T_host, uint64_t n, uin
 /* Same, text already in device memory of idx's device (copied device-to-device into the index). */
 int sa_hip_index_build_device(sa_hip_index* idx, const void* T_dev, uint64_t n, uint32_t max_suffix_length);
 /* Adopt an existing suffix array (host pointers): uploads T and SA and prepares the query
- * structures; SA must be sorted by the first max_suffix_length bytes (0 = fully sorted). */
+ * structures; SA must be sorted by the first max_suffix_length bytes (0 = fully sorted).
+ * Every entry is range-checked on the device: an array with an entry >= n is refused (-1). */
 int sa_hip_index_load(sa_hip_index* idx, const uint8_t* T_host, const uint32_t* SA_host, uint64_t n,
                       uint32_t max_suffix_length);
 /* Same with device pointers (multi-GPU replicas: T and SA arrive by RCCL broadcast). */
@@ -118,6 +119,11 @@ void* sa_hip_index_stream(const sa_hip_index* idx);
  * layout, widened on the device). */
 int sa_hip_index_get_sa_u32(sa_hip_index* idx, uint32_t* out_host);
 int sa_hip_index_get_sa_i64(sa_hip_index* idx, int64_t* out_host);
+/* The suffix array in libsais64 layout, device to device: out_dev[i] = (int64_t)SA[i] for i in [0, n), out_dev a
+ * device buffer of n * 8 bytes on the index's device (libsais64.c:6248-6259 widens in place on the CPU; this is
+ * the same pass as one kernel, 12 bytes of HBM traffic per entry).  Asynchronous on the index's stream; its
+ * HIP-event time is reported as sa_hip_build_stats.widen_ms. */
+int sa_hip_index_widen_device(sa_hip_index* idx, void* out_dev);
 /* 256-bin byte histogram of the indexed text (libsais `freq`). */
 int sa_hip_index_get_freq(sa_hip_index* idx, uint64_t* freq256);
 
@@ -130,7 +136,8 @@ int sa_hip_index_get_freq(sa_hip_index* idx, uint64_t* freq256);
 int sa_hip_query_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_t* offsets, uint64_t Q,
                        sa_hip_pair_u32* out);
 /* Same with every buffer in device memory (no copies; asynchronous on the index's stream
- * until sa_hip_index_sync). */
+ * until sa_hip_index_sync).  patterns_dev must stay readable for 8 bytes past offsets[Q]: a pattern's last
+ * partial 8-byte word is loaded whole and masked (the host-pointer form pads its staging copy itself). */
 int sa_hip_query_batch_device(sa_hip_index* idx, const void* patterns_dev, const void* offsets_dev,
                               uint64_t Q, void* out_dev);
 /* Copy up to `cap` suffix positions SA[first .. first+count) to the host (hit materialisation). */
@@ -180,6 +187,7 @@ typedef struct sa_hip_build_stats {
     uint32_t pass_launches[4];
     uint32_t text_top_pass;      /* 1: kernel [1] was text_top_pass_kernel<512> (keys assembled from the text) */
     uint32_t narrow_k;           /* 1: the index keeps u32 narrow keys + 257 bucket bounds as its query key array   */
+    double   widen_ms;           /* HIP-event time of the last sa_hip_index_widen_device after this build (0: none)  */
 } sa_hip_build_stats;
 int sa_hip_index_build_stats(const sa_hip_index* idx, sa_hip_build_stats* out);
 

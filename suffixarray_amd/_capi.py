@@ -22,7 +22,7 @@ EXPORTS = [
     "sa_hip_device_count", "sa_hip_index_create", "sa_hip_index_destroy", "sa_hip_index_build",
     "sa_hip_index_build_device", "sa_hip_index_load", "sa_hip_index_load_device", "sa_hip_index_n",
     "sa_hip_index_max_suffix_length", "sa_hip_index_text_dev", "sa_hip_index_sa_dev",
-    "sa_hip_index_stream", "sa_hip_index_get_sa_u32", "sa_hip_index_get_sa_i64",
+    "sa_hip_index_stream", "sa_hip_index_get_sa_u32", "sa_hip_index_get_sa_i64", "sa_hip_index_widen_device",
     "sa_hip_index_get_freq", "sa_hip_query_batch", "sa_hip_query_batch_device",
     "sa_hip_index_get_sa_range", "sa_hip_index_query_hits", "sa_hip_index_sync", "sa_hip_index_verify", "sa_hip_index_build_stats",
     "sa_hip_index_query_stats", "sa_hip_csv_extract_column", "sa_hip_csv_free", "sa_hip_synth_csv", "sa_hip_sort_pairs", "sa_hip_synth_uniform27", "sa_hip_last_error", "sa_hip_version",
@@ -48,7 +48,7 @@ class BuildStats(C.Structure):
                 ("tiny_resolved", C.c_uint64),
                 ("radix_ms", C.c_double), ("total_ms", C.c_double),
                 ("pass_ms", C.c_double * 4), ("pass_bytes", C.c_uint64 * 4), ("pass_launches", C.c_uint32 * 4),
-                ("text_top_pass", C.c_uint32), ("narrow_k", C.c_uint32)]
+                ("text_top_pass", C.c_uint32), ("narrow_k", C.c_uint32), ("widen_ms", C.c_double)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if k.startswith("pass_") else getattr(self, k)) for k, _ in self._fields_}
@@ -123,6 +123,8 @@ def lib():
     L.sa_hip_index_get_sa_u32.argtypes = [vp, vp]
     L.sa_hip_index_get_sa_i64.restype = C.c_int
     L.sa_hip_index_get_sa_i64.argtypes = [vp, vp]
+    L.sa_hip_index_widen_device.restype = C.c_int
+    L.sa_hip_index_widen_device.argtypes = [vp, vp]
     L.sa_hip_index_get_freq.restype = C.c_int
     L.sa_hip_index_get_freq.argtypes = [vp, vp]
     L.sa_hip_query_batch.restype = C.c_int
@@ -252,6 +254,10 @@ class DeviceIndex:
         out = np.empty(max(self.n, 1), dtype=np.int64)
         check(self._lib.sa_hip_index_get_sa_i64(self._h, out.ctypes.data))
         return out[:self.n]
+
+    def widen_device(self, out_dev_ptr):
+        """int64[n] libsais64-layout copy of the suffix array into a device buffer (asynchronous)."""
+        check(self._lib.sa_hip_index_widen_device(self._h, out_dev_ptr))
 
     def sa_range(self, first, count):
         out = np.empty(max(count, 1), dtype=np.uint32)

@@ -17,7 +17,10 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -216,6 +219,31 @@ inline void csv_parse_range(const u8* d, u64 n, u64 begin, u64 hi, u32 ci, CsvPa
     }
 }
 
+// fn(k) for k in [0, parts) on one thread each.  A thread that cannot be created (process / cgroup limit:
+// std::system_error) has its share run on the calling thread instead; every thread that was started is joined
+// before this returns or unwinds, so an exception of fn's (bad_alloc) reaches the extern "C" wrapper's catch
+// instead of std::terminate.
+template <class F>
+inline void csv_parallel(u64 parts, F&& fn) {
+    struct Group {
+        std::vector<std::thread> th;
+        ~Group() { for (auto& t : th) if (t.joinable()) t.join(); }
+    } g;
+    std::exception_ptr first;
+    std::mutex mu;
+    auto guarded = [&](u64 k) {
+        try { fn(k); }
+        catch (...) { std::lock_guard<std::mutex> l(mu); if (!first) first = std::current_exception(); }
+    };
+    g.th.reserve((size_t)parts);
+    for (u64 k = 0; k < parts; ++k) {
+        try { g.th.emplace_back(guarded, k); }
+        catch (const std::system_error&) { guarded(k); }
+    }
+    for (auto& t : g.th) t.join();
+    if (first) std::rethrow_exception(first);
+}
+
 // Multi-threaded: the file is cut into byte ranges; the quote parity in front of every range (a '"'
 // toggles it; the doubled quote of RFC-4180 toggles twice) tells whether a newline there is a row
 // terminator, so every worker can find the first row that starts inside its range on its own.
@@ -239,6 +267,11 @@ inline int csv_extract_column(const char* path, const char* column, sa_hip_csv_c
     void* map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (map == MAP_FAILED) return fail(SA_HIP_ENOMEM, "sa_hip_csv_extract_column: mmap failed", path);
+    struct Unmap {   // also on the unwinding path (an exception of a worker ends in the extern "C" wrapper's catch)
+        void* p; u64 n;
+        void release() { if (p) munmap(p, n); p = nullptr; }
+        ~Unmap() { release(); }
+    } mapping{map, n};
     const u8* d = static_cast<const u8*>(map);
     CsvRecordCursor cur{d, n, 0};
 
@@ -248,7 +281,7 @@ inline int csv_extract_column(const char* path, const char* column, sa_hip_csv_c
     csv_parse_record<true>(cur, &header, 0, nullptr, &rs, &re, &f0e);
     int ci = -1;
     for (size_t k = 0; k < header.size(); ++k) if (header[k] == column) { ci = (int)k; break; }
-    if (ci < 0) { munmap(map, n); return fail(SA_HIP_EINVAL, "sa_hip_csv_extract_column: column not found", column); }
+    if (ci < 0) { mapping.release(); return fail(SA_HIP_EINVAL, "sa_hip_csv_extract_column: column not found", column); }
     const u64 body = re;   // first byte after the header row
 
     // ranges
@@ -265,10 +298,7 @@ inline int csv_extract_column(const char* path, const char* column, sa_hip_csv_c
     // pass 1: quote counts per range -> parity in front of each range
     std::vector<u64> quotes(parts_n, 0);
     {
-        std::vector<std::thread> th;
-        for (u64 k = 0; k < parts_n; ++k)
-            th.emplace_back([&, k]() { u64 c = 0; for (u64 i = lo[k]; i < lo[k + 1]; ++i) c += (d[i] == '"'); quotes[k] = c; });
-        for (auto& t : th) t.join();
+        csv_parallel(parts_n, [&](u64 k) { u64 c = 0; for (u64 i = lo[k]; i < lo[k + 1]; ++i) c += (d[i] == '"'); quotes[k] = c; });
     }
     lap("quote parity (first touch)");
     // start of the first record of every range: after the first newline outside quotes at or after lo[k]
@@ -298,13 +328,10 @@ inline int csv_extract_column(const char* path, const char* column, sa_hip_csv_c
     // pass 2: parse the rows that start in [begin[k], begin[k+1])
     std::vector<CsvPart> part(parts_n);
     {
-        std::vector<std::thread> th;
-        for (u64 k = 0; k < parts_n; ++k)
-            th.emplace_back([&, k]() { if (begin[k] < begin[k + 1]) csv_parse_range(d, n, begin[k], begin[k + 1], (u32)ci, part[k]); });
-        for (auto& t : th) t.join();
+        csv_parallel(parts_n, [&](u64 k) { if (begin[k] < begin[k + 1]) csv_parse_range(d, n, begin[k], begin[k + 1], (u32)ci, part[k]); });
     }
     lap("parse");
-    munmap(map, n);
+    mapping.release();
 
     u64 tlen = 0, rows = 0, last_end = 0;
     for (auto& p : part) { tlen += p.text.size(); rows += p.starts.size(); if (!p.starts.empty()) last_end = p.last_end; }
@@ -327,9 +354,7 @@ inline int csv_extract_column(const char* path, const char* column, sa_hip_csv_c
     {
         std::vector<u64> toff(parts_n + 1, 0), roff(parts_n + 1, 0);
         for (u64 k = 0; k < parts_n; ++k) { toff[k + 1] = toff[k] + part[k].text.size(); roff[k + 1] = roff[k] + part[k].starts.size(); }
-        std::vector<std::thread> th;
-        for (u64 k = 0; k < parts_n; ++k)
-            th.emplace_back([&, k]() {
+        csv_parallel(parts_n, [&](u64 k) {
                 CsvPart& p = part[k];
                 if (!p.text.empty()) memcpy(out->text + toff[k], p.text.data(), p.text.size());
                 for (size_t r = 0; r < p.starts.size(); ++r) {
@@ -340,7 +365,6 @@ inline int csv_extract_column(const char* path, const char* column, sa_hip_csv_c
                 std::vector<u64>().swap(p.starts);
                 std::vector<u64>().swap(p.offs);
             });
-        for (auto& t : th) t.join();
     }
     lap("merge into output arrays");
     out->row_file_offsets[rows] = rows ? last_end : 0;

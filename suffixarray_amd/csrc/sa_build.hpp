@@ -739,9 +739,34 @@ __global__ __launch_bounds__(BLD_BLOCK) void scatter_ranks_kernel(const u8* __re
     }
 }
 
-__global__ void widen_kernel(const u32* __restrict__ sa, u64 n, int64_t* __restrict__ out) {
+// libsais64 layout (libsais64.c:6248-6259 widens in place on the CPU): out[i] = (int64)sa[i].  Four entries per
+// thread and step: one 16-byte load, two 16-byte stores (device allocations are 16-byte aligned; an odd base
+// address -- a caller's sub-range -- takes the element-wise loop).
+__global__ __launch_bounds__(256) void widen_kernel(const u32* __restrict__ sa, u64 n, int64_t* __restrict__ out) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (int64_t)sa[i];
+    const u64 t0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(sa) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+    u64 done = 0;
+    if (aligned) {
+        const u64 n4 = n / 4;
+        const uint4* __restrict__ in4 = reinterpret_cast<const uint4*>(sa);
+        uint4* __restrict__ out4 = reinterpret_cast<uint4*>(out);
+        for (u64 i = t0; i < n4; i += stride) {
+            const uint4 v = in4[i];
+            out4[2 * i] = make_uint4(v.x, 0u, v.y, 0u);
+            out4[2 * i + 1] = make_uint4(v.z, 0u, v.w, 0u);
+        }
+        done = n4 * 4;
+    }
+    for (u64 i = done + t0; i < n; i += stride) out[i] = (int64_t)sa[i];
+}
+
+// entries of an adopted suffix array that cannot be suffix positions (>= n): sa_hip_index_load refuses the array
+__global__ void sa_range_check_kernel(const u32* __restrict__ sa, u64 n, u64* __restrict__ bad) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u64 local = 0;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) local += (sa[j] >= n) ? 1u : 0u;
+    if (local) atomicAdd((unsigned long long*)bad, (unsigned long long)local);
 }
 
 // ---- on-device verification (sufcheck) ----------------------------------------------

@@ -1,6 +1,7 @@
 // sa_capi.hip -- the C ABI of libsa_hip.so (include/sa_hip.h).  Single translation unit for
 // gfx950: hipcc --offload-arch=gfx950 -shared -fPIC.  No CPU fallback: every entry point needs
 // a HIP device and fails with SA_HIP_EHIP when there is none.
+#include <exception>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -25,6 +26,8 @@ struct sa_hip_index {
     u8* qh_host = nullptr;   // pinned, device-mapped block of sa_hip_index_query_hits (QH_BYTES)
     u8* qh_dev = nullptr;    // the same block as the device sees it
     hipEvent_t q_begin = nullptr, q_end = nullptr;
+    hipEvent_t w_begin = nullptr, w_end = nullptr;   // sa_hip_index_widen_device
+    double widen_ms = 0.0;                           // < 0: recorded, not yet resolved
     sa_hip_query_stats qstats{};
 };
 
@@ -116,7 +119,8 @@ int sa_hip_index_create(sa_hip_index** out, uint64_t n_max, int device) {
     if (e != hipSuccess) { delete idx; return fail(SA_HIP_EHIP, "hipStreamCreate", hipGetErrorString(e)); }
     rc = idx->b.init(n_max, idx->stream);
     if (!rc) {
-        if (hipEventCreate(&idx->q_begin) != hipSuccess || hipEventCreate(&idx->q_end) != hipSuccess)
+        if (hipEventCreate(&idx->q_begin) != hipSuccess || hipEventCreate(&idx->q_end) != hipSuccess ||
+            hipEventCreate(&idx->w_begin) != hipSuccess || hipEventCreate(&idx->w_end) != hipSuccess)
             rc = fail(SA_HIP_EHIP, "hipEventCreate");
     }
     if (rc) { sa_hip_index_destroy(idx); return rc; }
@@ -133,6 +137,8 @@ void sa_hip_index_destroy(sa_hip_index* idx) {
     if (idx->qh_host) (void)hipHostFree(idx->qh_host);
     if (idx->q_begin) (void)hipEventDestroy(idx->q_begin);
     if (idx->q_end) (void)hipEventDestroy(idx->q_end);
+    if (idx->w_begin) (void)hipEventDestroy(idx->w_begin);
+    if (idx->w_end) (void)hipEventDestroy(idx->w_end);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     delete idx;
 }
@@ -145,6 +151,7 @@ int sa_hip_index_build(sa_hip_index* idx, const uint8_t* T_host, uint64_t n, uin
     if (n > idx->b.n_max) return fail(SA_HIP_EINVAL, "sa_hip_index_build: n exceeds the index capacity");
     if (n) SA_HIP_CHECK(hipMemcpyAsync(idx->b.text.p, T_host, n, hipMemcpyHostToDevice, idx->stream));
     idx->has_index = false;
+    idx->widen_ms = 0.0;
     rc = idx->b.build(n, max_suffix_length);
     idx->has_index = (rc == 0);
     return rc;
@@ -159,6 +166,7 @@ int sa_hip_index_build_device(sa_hip_index* idx, const void* T_dev, uint64_t n, 
     if (n && T_dev != idx->b.text.p)
         SA_HIP_CHECK(hipMemcpyAsync(idx->b.text.p, T_dev, n, hipMemcpyDeviceToDevice, idx->stream));
     idx->has_index = false;
+    idx->widen_ms = 0.0;
     rc = idx->b.build(n, max_suffix_length);
     idx->has_index = (rc == 0);
     return rc;
@@ -171,12 +179,22 @@ static int load_common(sa_hip_index* idx, const void* T, const void* SA, uint64_
     if (n > idx->b.n_max) return fail(SA_HIP_EINVAL, "sa_hip_index_load: n exceeds the index capacity");
     Builder& b = idx->b;
     if ((rc = b.sa_own.ensure((size_t)(n ? n : 1) * 4))) return rc;
+    idx->has_index = false;
+    u64 bad_host = 0;
     if (n) {
         SA_HIP_CHECK(hipMemcpyAsync(b.text.p, T, n, kind, idx->stream));
         SA_HIP_CHECK(hipMemcpyAsync(b.sa_own.p, SA, (size_t)n * 4, kind, idx->stream));
+        // an entry >= n would send the query kernel's text reads out of bounds: refuse the array (the copy of the
+        // count rides on the synchronisation prepare_text() does anyway)
+        u64* bad = reinterpret_cast<u64*>(b.small.as<u8>() + 3072);
+        SA_HIP_CHECK(hipMemsetAsync(bad, 0, 8, idx->stream));
+        hipLaunchKernelGGL(sa_range_check_kernel, dim3(stream_grid(n, 1024)), dim3(256), 0, idx->stream,
+                           (const u32*)b.sa_own.p, n, bad);
+        SA_HIP_CHECK(hipMemcpyAsync(&bad_host, bad, 8, hipMemcpyDeviceToHost, idx->stream));
     }
     CodeMap map; u32 sigma; int bits;
     if ((rc = b.prepare_text(n, map, sigma, bits))) return rc;
+    if (bad_host) return fail(SA_HIP_EINVAL, "sa_hip_index_load: suffix array holds entries >= n");
     b.sa = b.sa_own.as<u32>();
     b.max_suffix_length = L;
     if ((rc = b.prepare_query_from_sa(map, bits, L))) return rc;
@@ -212,17 +230,19 @@ int sa_hip_index_sync(sa_hip_index* idx) {
 }
 
 int sa_hip_index_verify(sa_hip_index* idx, uint64_t* violations) {
-    if (!idx || !idx->has_index || !violations) return fail(SA_HIP_EINVAL, "sa_hip_index_verify: no index");
-    std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx || !violations) return fail(SA_HIP_EINVAL, "sa_hip_index_verify: NULL argument");
+    std::lock_guard<std::mutex> g(idx->mu);   // has_index / n are only read under the lock (a concurrent build rewrites them)
+    if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_verify: no index");
     int rc = set_device(idx->device);
     if (rc) return rc;
     return idx->b.verify(violations);
 }
 
 int sa_hip_index_get_sa_u32(sa_hip_index* idx, uint32_t* out_host) {
-    if (!idx || !idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_u32: no index");
-    if (!out_host && idx->b.n) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_u32: NULL output");
+    if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_u32: NULL index");
     std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_u32: no index");
+    if (!out_host && idx->b.n) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_u32: NULL output");
     int rc = set_device(idx->device);
     if (rc) return rc;
     if (idx->b.n) SA_HIP_CHECK(hipMemcpyAsync(out_host, idx->b.sa, (size_t)idx->b.n * 4, hipMemcpyDeviceToHost, idx->stream));
@@ -231,9 +251,10 @@ int sa_hip_index_get_sa_u32(sa_hip_index* idx, uint32_t* out_host) {
 }
 
 int sa_hip_index_get_sa_i64(sa_hip_index* idx, int64_t* out_host) {
-    if (!idx || !idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_i64: no index");
-    if (!out_host && idx->b.n) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_i64: NULL output");
+    if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_i64: NULL index");
     std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_i64: no index");
+    if (!out_host && idx->b.n) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_i64: NULL output");
     int rc = set_device(idx->device);
     if (rc) return rc;
     const u64 n = idx->b.n;
@@ -252,11 +273,29 @@ int sa_hip_index_get_sa_i64(sa_hip_index* idx, int64_t* out_host) {
     return 0;
 }
 
+int sa_hip_index_widen_device(sa_hip_index* idx, void* out_dev) {
+    if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_widen_device: NULL index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_widen_device: no index");
+    const u64 n = idx->b.n;
+    if (!out_dev && n) return fail(SA_HIP_EINVAL, "sa_hip_index_widen_device: NULL output");
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    SA_HIP_CHECK(hipEventRecord(idx->w_begin, idx->stream));
+    if (n) hipLaunchKernelGGL(widen_kernel, dim3(stream_grid(n / 4 + 1, 256)), dim3(256), 0, idx->stream, (const u32*)idx->b.sa, n,
+                              static_cast<int64_t*>(out_dev));
+    SA_HIP_CHECK(hipEventRecord(idx->w_end, idx->stream));
+    SA_HIP_CHECK(hipGetLastError());
+    idx->widen_ms = -1.0;   // resolved by sa_hip_index_build_stats
+    return 0;
+}
+
 int sa_hip_index_get_sa_range(sa_hip_index* idx, uint64_t first, uint64_t count, uint32_t* out_host) {
-    if (!idx || !idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: no index");
+    if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: NULL index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: no index");
     if (first > idx->b.n || count > idx->b.n - first) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: out of range");
     if (!out_host && count) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: NULL output");
-    std::lock_guard<std::mutex> g(idx->mu);
     int rc = set_device(idx->device);
     if (rc) return rc;
     if (count) SA_HIP_CHECK(hipMemcpyAsync(out_host, idx->b.sa + first, (size_t)count * 4, hipMemcpyDeviceToHost, idx->stream));
@@ -272,12 +311,13 @@ int sa_hip_index_get_freq(sa_hip_index* idx, uint64_t* freq256) {
 
 int sa_hip_query_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_t* offsets, uint64_t Q,
                        sa_hip_pair_u32* out) {
-    if (!idx || !idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_query_batch: no index");
+    if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_query_batch: NULL index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_query_batch: no index");
     if (Q == 0) return 0;
     if (!offsets || !out) return fail(SA_HIP_EINVAL, "sa_hip_query_batch: NULL argument");
     const u64 total = offsets[Q];
     if (!patterns && total) return fail(SA_HIP_EINVAL, "sa_hip_query_batch: NULL patterns");
-    std::lock_guard<std::mutex> g(idx->mu);
     int rc = set_device(idx->device);
     if (rc) return rc;
     if ((rc = idx->q_pat.ensure((size_t)total + 64))) return rc;
@@ -294,11 +334,12 @@ int sa_hip_query_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_
 
 int sa_hip_index_query_hits(sa_hip_index* idx, const uint8_t* pattern, uint64_t len, uint32_t max_hits,
                             sa_hip_pair_u32* range, uint32_t* hits, uint32_t* nhits) {
-    if (!idx || !idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_query_hits: no index");
+    if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_query_hits: NULL index");
     if (!range || !nhits || (!pattern && len) || (!hits && max_hits)) return fail(SA_HIP_EINVAL, "sa_hip_index_query_hits: NULL argument");
     if (len > QH_BYTES - 64 - QH_OFF_PATTERN) return fail(SA_HIP_EINVAL, "sa_hip_index_query_hits: pattern longer than 47 KB");
     if (max_hits > QH_MAX_HITS) max_hits = QH_MAX_HITS;
     std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_query_hits: no index");
     int rc = set_device(idx->device);
     if (rc) return rc;
     if (!idx->qh_host) {
@@ -326,18 +367,30 @@ int sa_hip_index_query_hits(sa_hip_index* idx, const uint8_t* pattern, uint64_t 
 
 int sa_hip_query_batch_device(sa_hip_index* idx, const void* patterns_dev, const void* offsets_dev, uint64_t Q,
                               void* out_dev) {
-    if (!idx || !idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_query_batch_device: no index");
+    if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_query_batch_device: NULL index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_query_batch_device: no index");
     if (Q == 0) return 0;
     if (!patterns_dev || !offsets_dev || !out_dev) return fail(SA_HIP_EINVAL, "sa_hip_query_batch_device: NULL argument");
-    std::lock_guard<std::mutex> g(idx->mu);
     int rc = set_device(idx->device);
     if (rc) return rc;
     return launch_query(idx, (const u8*)patterns_dev, (const u64*)offsets_dev, Q, (sa_hip_pair_u32*)out_dev);
 }
 
-int sa_hip_index_build_stats(const sa_hip_index* idx, sa_hip_build_stats* out) {
+int sa_hip_index_build_stats(const sa_hip_index* idx_c, sa_hip_build_stats* out) {
+    sa_hip_index* idx = const_cast<sa_hip_index*>(idx_c);
     if (!idx || !out) return fail(SA_HIP_EINVAL, "sa_hip_index_build_stats: NULL argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->widen_ms < 0.0) {
+        int rc = set_device(idx->device);
+        if (rc) return rc;
+        SA_HIP_CHECK(hipEventSynchronize(idx->w_end));
+        float ms = 0.f;
+        SA_HIP_CHECK(hipEventElapsedTime(&ms, idx->w_begin, idx->w_end));
+        idx->widen_ms = ms;
+    }
     *out = idx->b.stats;
+    out->widen_ms = idx->widen_ms;
     return 0;
 }
 
@@ -471,12 +524,27 @@ int sa_hip_sort_pairs(uint64_t* keys, uint32_t* values, uint64_t n, int begin_bi
 
 int sa_hip_csv_extract_column(const char* path, const char* column, sa_hip_csv_column* out) {
     if (!path || !column || !out) return fail(SA_HIP_EINVAL, "sa_hip_csv_extract_column: NULL argument");
-    return csv_extract_column(path, column, out);
+    // nothing may unwind through the C ABI: allocation failures and thread-creation failures become codes
+    try {
+        return csv_extract_column(path, column, out);
+    } catch (const std::bad_alloc&) {
+        csv_free(out);
+        return fail(SA_HIP_ENOMEM, "sa_hip_csv_extract_column: out of host memory");
+    } catch (const std::exception& e) {
+        csv_free(out);
+        return fail(SA_HIP_EINVAL, "sa_hip_csv_extract_column", e.what());
+    }
 }
 void sa_hip_csv_free(sa_hip_csv_column* col) { csv_free(col); }
 int sa_hip_synth_csv(const char* path, uint64_t rows, uint64_t seed) {
     if (!path) return fail(SA_HIP_EINVAL, "sa_hip_synth_csv: NULL path");
-    return synth_csv(path, rows, seed);
+    try {
+        return synth_csv(path, rows, seed);
+    } catch (const std::bad_alloc&) {
+        return fail(SA_HIP_ENOMEM, "sa_hip_synth_csv: out of host memory");
+    } catch (const std::exception& e) {
+        return fail(SA_HIP_EINVAL, "sa_hip_synth_csv", e.what());
+    }
 }
 
 void sa_hip_synth_uniform27(uint8_t* out, uint64_t n, uint64_t seed) {

@@ -51,7 +51,7 @@ __device__ __forceinline__ u64 pattern_word(const u8* q, u32 c, u32 j) {
 template <int WORDS>
 __device__ __forceinline__ int cmp_suffix(const u8* __restrict__ text, u64 n, u32 pos, const u64 (&qw)[WORDS],
                                           const u8* __restrict__ q, u32 c) {
-    const u64 avail = n - pos;
+    const u64 avail = (pos < n) ? n - pos : 0;   // (an adopted SA is range-checked on load; this keeps a stale entry harmless)
     const u32 l = avail < c ? (u32)avail : c;  // bytes of the suffix that exist
     const u8* s = text + pos;
     u32 i = 0;

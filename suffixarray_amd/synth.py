@@ -71,20 +71,38 @@ def fibonacci(n):
     return np.frombuffer(b[:n], dtype=np.uint8).copy()
 
 
-def query_batch(text, q, m=16, seed=0):
-    """Q patterns of m bytes (packed, offsets): even i = text window at
-    pos = ((i * 0x9E3779B97F4A7C15) >> 11) % (N - m) with '\\n' replaced by 'a'; odd i = uniform
-    random lower-case string.  Returns (uint8[Q*m], uint64[Q+1])."""
+def _splitmix64(x):
+    """Vectorised splitmix64 finaliser (uint64 array in, uint64 array out)."""
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def query_batch(text, q, m=16, seed=0, lo=0, hi=None):
+    """Patterns lo..hi-1 (default: all) of the batch of Q = q patterns of m bytes (packed, offsets): even i = text
+    window at pos = ((i * 0x9E3779B97F4A7C15) >> 11) % (N - m) with '\n' replaced by 'a'; odd i = uniform random
+    lower-case string.  Every pattern is a function of (i, seed) alone, so a rank's slice of the global batch
+    (bench.py --gpus N) is generated without the rest.  Returns (uint8[(hi-lo)*m], uint64[hi-lo+1])."""
     n = text.size
-    i = np.arange(q, dtype=np.uint64)
+    hi = q if hi is None else hi
+    cnt = hi - lo
+    i = np.arange(lo, hi, dtype=np.uint64)
     with np.errstate(over="ignore"):
         pos = ((i * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(11)) % np.uint64(max(n - m, 1))
     pos = pos.astype(np.int64)
-    win = text[pos[:, None] + np.arange(m)[None, :]] if n >= m else np.full((q, m), 97, np.uint8)
+    win = text[pos[:, None] + np.arange(m)[None, :]] if n >= m else np.full((cnt, m), 97, np.uint8)
     win = np.where(win == 10, 97, win).astype(np.uint8)
-    rng = np.random.default_rng(seed + 99)
-    rnd = rng.integers(97, 123, (q, m), dtype=np.uint8)
-    odd = (np.arange(q) & 1).astype(bool)
+    words = (m + 7) // 8
+    with np.errstate(over="ignore"):
+        h = _splitmix64(i * np.uint64(0xD1342543DE82EF95) + np.uint64((seed + 99) & 0xFFFFFFFF))
+    cols = []
+    for _ in range(words):
+        cols.append(h.copy().view(np.uint8).reshape(cnt, 8))
+        h = _splitmix64(h)
+    rnd = (np.concatenate(cols, axis=1)[:, :m] % 26 + 97).astype(np.uint8) if cnt else np.zeros((0, m), np.uint8)
+    odd = (np.arange(lo, hi) & 1).astype(bool)
     pats = np.where(odd[:, None], rnd, win).astype(np.uint8)
-    off = (np.arange(q + 1, dtype=np.uint64) * np.uint64(m))
+    off = (np.arange(cnt + 1, dtype=np.uint64) * np.uint64(m))
     return np.ascontiguousarray(pats.reshape(-1)), off

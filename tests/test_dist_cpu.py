@@ -1,6 +1,7 @@
-"""CPU: the N > 1 path of the batched query (suffixarray_amd/distributed.py) with world_size 2 on the
-gloo backend.  The per-rank search is the oracle here (no GPU in this container); on the GPU box the
-same function wraps DeviceIndex.query_batch (bench.py)."""
+"""CPU: the N > 1 path of the batched query (suffixarray_amd/distributed.py: broadcast_index, shard_bounds,
+ShardedBatch.step / results -- the functions bench.py --gpus N runs) with world_size 2 on the gloo backend.
+The per-rank searcher is the oracle here (no GPU in this container); on the GPU box it is
+DeviceIndex.query_batch_device."""
 import os
 import socket
 
@@ -28,10 +29,12 @@ def _worker(rank, world, port, q, tmp):
     sys.path.insert(0, root)
     from oracle.oracle import Oracle
     from suffixarray_amd import synth
-    from suffixarray_amd.distributed import broadcast_index, shard_bounds, sharded_query
+    from suffixarray_amd.distributed import ShardedBatch, broadcast_index, shard_bounds
     o = Oracle()
     n = 200_000
-    # rank 0 "builds"; the index reaches the other rank only through the broadcast
+    m = 12
+    dev = torch.device("cpu")
+    # rank 0 "builds"; the index reaches the other rank only through the broadcast (bench.py: run_sharded)
     if rank == 0:
         text = synth.d1_uniform27(n)
         sa = o.sais(text).astype(np.int32)
@@ -42,20 +45,29 @@ def _worker(rank, world, port, q, tmp):
     text = tx_t.numpy()
     sa = sa_t.numpy().astype(np.uint32)
     ref_text = synth.d1_uniform27(n)
-    buf, off = synth.query_batch(ref_text, q, 12)
-
-    def local(pat, offs):
-        return o.query_batch(text, sa, 0xFFFFFFFF, (pat, offs), threads=1)
-
-    got = sharded_query(local, buf, off, world, rank, torch.device("cpu"))
-    exp = o.query_batch(ref_text, o.sais(ref_text).astype(np.uint32), 0xFFFFFFFF, (buf, off), threads=1)
-    ok = np.array_equal(got["first"], exp["first"]) and np.array_equal(got["second"], exp["second"])
+    # ONE global batch; this rank generates and holds only its slice
     lo, hi = shard_bounds(q, world, rank)
+    buf, off = synth.query_batch(ref_text, q, m, lo=lo, hi=hi)
+    batch = ShardedBatch(buf, off, q, world, rank, dev)
+
+    def search(pat_t, off_t, q_local, out_t):
+        # the local searcher of the CPU test is the oracle; on the GPU it is sa_hip_query_batch_device
+        pat = pat_t.numpy()
+        offs = off_t.numpy().view(np.uint64)
+        res = o.query_batch(text, sa, 0xFFFFFFFF, (pat[:int(offs[-1])], offs), threads=1)
+        out_t[:2 * q_local] = torch.from_numpy(res.view(np.uint32).view(np.int32).copy())
+
+    for _ in range(2):   # the buffers are reused from step to step
+        batch.step(search)
+    got = batch.results()
+    fb, fo = synth.query_batch(ref_text, q, m)
+    exp = o.query_batch(ref_text, o.sais(ref_text).astype(np.uint32), 0xFFFFFFFF, (fb, fo), threads=1)
+    ok = np.array_equal(got["first"], exp["first"]) and np.array_equal(got["second"], exp["second"])
     np.save(os.path.join(tmp, f"r{rank}.npy"), np.array([int(ok), lo, hi]))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("q", [1001, 7])
+@pytest.mark.parametrize("q", [1001, 7, 1])
 def test_sharded_query_world2_gloo(tmp_path, q):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), q, str(tmp_path)), nprocs=world, join=True)

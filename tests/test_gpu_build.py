@@ -188,3 +188,44 @@ def test_rounds_sorted_in_lds_match_global_sort(gpu, oracle, monkeypatch):
         # the global sort launches fewer passes when the rounds go through LDS
         if name in ("words", "blocks"):
             assert stats["1"]["radix_passes"] < stats["0"]["radix_passes"], (name, stats)
+
+
+def test_load_refuses_suffix_array_with_out_of_range_entries(gpu, oracle):
+    """An adopted SA is range-checked on the device: an entry >= n would send the query kernel's text reads out of
+    bounds, so sa_hip_index_load returns SA_HIP_EINVAL instead of adopting it."""
+    t = cases.small_texts()["d2_300k"]
+    sa = oracle.sais(t).astype(np.uint32)
+    with gpu.DeviceIndex(t.size, 0) as idx:
+        idx.load(t, sa, 0)
+        assert idx.verify() == 0
+        for bad_value in (t.size, t.size + 12345, 0xFFFFFFFF):
+            bad = sa.copy()
+            bad[t.size // 2] = bad_value
+            with pytest.raises(gpu.SaHipError) as e:
+                idx.load(t, bad, 0)
+            assert e.value.code == -1
+            with pytest.raises(gpu.SaHipError):   # and the handle holds no index afterwards
+                idx.query_batch([b"the"])
+        idx.load(t, sa, 0)   # a good array is adopted again
+        assert idx.query_batch([b"a"])["first"][0] != 0xFFFFFFFF
+
+
+def test_widen_device_is_the_libsais64_layout(gpu, oracle):
+    """sa_hip_index_widen_device (the pass bench.py times as part of the 64-bit SA build): int64[n] == (int64)SA,
+    for sizes that exercise the 16-byte body and the element-wise tail."""
+    import torch
+    texts = cases.small_texts()
+    for name in ("d2_300k", "banana", "len1"):
+        t = texts[name] if name in texts else np.frombuffer(name.encode(), np.uint8)
+        for cut in (0, 1, 3):
+            tt = t[:t.size - cut] if t.size > cut else t
+            with gpu.DeviceIndex(max(tt.size, 1), 0) as idx:
+                idx.build(tt)
+                out = torch.full((tt.size + 4,), -7, dtype=torch.int64, device="cuda:0")
+                torch.cuda.synchronize()
+                idx.widen_device(out.data_ptr())
+                idx.sync()
+                got = out.cpu().numpy()
+                assert np.array_equal(got[:tt.size], oracle.sais(tt).astype(np.int64)), (name, cut)
+                assert (got[tt.size:] == -7).all()
+                assert idx.build_stats()["widen_ms"] >= 0.0
