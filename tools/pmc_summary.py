@@ -1,57 +1,123 @@
-"""Summarise two rocprofv3 --pmc runs of bench.py (FETCH_SIZE and WRITE_SIZE, separate passes) into
-profiles/pmc_onesweep.json + the per-dispatch CSVs kept beside it.
+"""Summarise the rocprofv3 --pmc runs of tools/gpu_profiles.sh <tag> (FETCH_SIZE, WRITE_SIZE and the raw L2
+memory-side request counters, separate passes over `bench.py --steps 1 --warmup 0`) into
 
-    python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <tag> [kernel name substring]
+    profiles/pmc_onesweep.json            dominant sort kernel: HBM bytes per launch
+    profiles/pmc_query.json               query_kernel: HBM bytes + 64-byte requests per 1M-query launch
+    profiles/<tag>_pmc_{fetch,write,raw}.csv   the per-dispatch counters of the kernels of a build + the query batch
+    profiles/<tag>_pmc_calibration.md     FETCH_SIZE on random 4-/8-byte reads (tools/gatherbench), if that pass ran
 
-Corrections (profiles/r01_c_pmc_calibration.md): counters are in KiB; on gfx950 FETCH_SIZE counts 64 B
-per 128-B request, i.e. half of the bytes (re-calibrated with 8- and 4-byte-per-lane copy kernels);
-WRITE_SIZE is exact."""
-import csv, json, os, sys
+    python tools/pmc_summary.py <tag> [n_chars] [queries]
+
+Corrections (MI355X_MICROARCH.md, HBM section; profiles/r01_c_pmc_calibration.md; <tag>_pmc_calibration.md):
+counters are in KiB; FETCH_SIZE = requests x 64 B: a wide coalesced streaming read goes out as 128-byte requests and
+is under-counted by exactly 2 (x2 for the streaming sort kernels), a RANDOM narrow read is one 64-byte request and is
+counted exactly (x1 for query_kernel; the raw pass shows TCC_EA0_RDREQ_32B = TCC_BUBBLE = 0 and
+TCC_EA0_RDREQ x 64 B = FETCH_SIZE for it); WRITE_SIZE is exact."""
+import csv
+import glob
+import json
+import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = sys.argv[4] if len(sys.argv) > 4 else "seg_onesweep_kernel<512, 24, false, true>"   # substring of the rocprofv3 kernel name
+SORT_KERNEL = "seg_onesweep_kernel<512, 24, false, true>"
+KEEP = ("onesweep", "text_top_pass", "query_kernel", "flags_kernel", "seg_hist", "top_hist", "byte_hist", "compact", "widen", "gather_kernel",
+        "loc_sort", "chunk_keys", "tiny_groups")
 
 
-def rows(path, counter):
+def counter_file(tag, what):
+    g = glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{what}", "*", "*_counter_collection.csv"))
+    return g[0] if g else None
+
+
+def rows(path):
     out = []
+    if not path:
+        return out
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and KERNEL in r["Kernel_Name"]:
-            out.append((int(r["Dispatch_Id"]), r["Kernel_Name"], int(r["Grid_Size"]), float(r["Counter_Value"])))
+        name = r["Kernel_Name"].split("(")[0].replace("void sa::", "").replace("void ", "")
+        out.append((int(r["Dispatch_Id"]), name, int(r["Grid_Size"]), r["Counter_Name"], float(r["Counter_Value"])))
     return sorted(out)
 
 
+def keep_csv(tag, what, data):
+    if not data:
+        return
+    with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{what}.csv"), "w") as o:
+        o.write("Dispatch_Id,Kernel_Name,Grid_Size,Counter_Name,Counter_Value\n")
+        for d, k, g, c, v in data:
+            if any(s in k for s in KEEP):
+                o.write("%d,\"%s\",%d,%s,%f\n" % (d, k, g, c, v))
+
+
 def main():
-    fetch_csv, write_csv, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-    f = rows(fetch_csv, "FETCH_SIZE")
-    w = rows(write_csv, "WRITE_SIZE")
-    assert f and len(f) == len(w), (len(f), len(w))
-    big = max(g for _, _, g, _ in f)
-    fb = [v * 1024.0 * 2.0 for _, _, g, v in f if g == big]
-    wb = [v * 1024.0 for _, _, g, v in w if g == big]
-    n = len(fb)
-    for name, data, cname in (("fetch", f, "FETCH_SIZE"), ("write", w, "WRITE_SIZE")):
-        with open(os.path.join(ROOT, "profiles", "%s_pmc_%s_onesweep_n1e9.csv" % (tag, name)), "w") as o:
-            o.write("Dispatch_Id,Kernel_Name,Grid_Size,Counter_Name,Counter_Value_KB\n")
-            for d, k, g, v in data:
-                o.write("%d,%s,%d,%s,%f\n" % (d, k.split("(")[0].replace("void sa::", ""), g, cname, v))
-    j = {
-        "kernel": KERNEL,
-        "workload": "bench.py default: D1 uniform27 N=1e9, k0=8 (40-bit keys): top-digit pass + 3 passes of this kernel + last pass per build",
-        "launches": n,
-        "fetch_bytes_total": sum(fb),
-        "write_bytes_total": sum(wb),
-        "traffic_bytes_per_launch": (sum(fb) + sum(wb)) / n,
-        "algorithmic_bytes_per_launch": 16000000000.0 if "seg_onesweep_kernel<512, 24, false, true>" in KERNEL else None,
-        "corrections": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request; calibrated with 8-byte and 4-byte-per-lane copy "
-                       "kernels in tools/sortbench.hip), WRITE_SIZE exact, counters in KiB",
-        "commands": [
-            "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
-            "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
-        ],
-        "source": [os.path.basename(fetch_csv), os.path.basename(write_csv), tag],
-    }
-    json.dump(j, open(os.path.join(ROOT, "profiles", "pmc_onesweep.json"), "w"), indent=1)
-    print(json.dumps(j, indent=1))
+    tag = sys.argv[1]
+    n_chars = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000_000
+    queries = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
+    fetch, write, raw = rows(counter_file(tag, "fetch")), rows(counter_file(tag, "write")), rows(counter_file(tag, "raw"))
+    for what, data in (("fetch", fetch), ("write", write), ("raw", raw)):
+        keep_csv(tag, what, data)
+    light = "--no-cpu-baseline --no-secondary"
+    cmds = [f"rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 {light}",
+            f"rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 {light}"]
+
+    # ---- dominant sort kernel ----------------------------------------------------------------------------
+    f = [(g, v) for _, k, g, c, v in fetch if c == "FETCH_SIZE" and SORT_KERNEL in k]
+    w = [(g, v) for _, k, g, c, v in write if c == "WRITE_SIZE" and SORT_KERNEL in k]
+    if f and len(f) == len(w):
+        big = max(g for g, _ in f)
+        fb = [v * 1024.0 * 2.0 for g, v in f if g == big]
+        wb = [v * 1024.0 for g, v in w if g == big]
+        j = {"kernel": SORT_KERNEL, "n_chars": n_chars,
+             "workload": "bench.py default: D1 uniform27 N=1e9, k0=8 (40-bit keys): top-digit pass + 3 passes of this kernel + last pass per build",
+             "launches": len(fb), "fetch_bytes_total": sum(fb), "write_bytes_total": sum(wb),
+             "traffic_bytes_per_launch": (sum(fb) + sum(wb)) / len(fb), "algorithmic_bytes_per_launch": 16.0 * n_chars,
+             "corrections": "FETCH_SIZE x2 (wide coalesced reads leave the L2 as 128-byte requests tallied at 64 B; calibrated with 8- and "
+                            "4-byte-per-lane copy kernels, tools/sortbench.hip), WRITE_SIZE exact, counters in KiB",
+             "commands": cmds, "source": tag}
+        json.dump(j, open(os.path.join(ROOT, "profiles", "pmc_onesweep.json"), "w"), indent=1)
+        print(json.dumps(j, indent=1))
+
+    # ---- query kernel: one launch per bench step -------------------------------------------------------------------
+    qf = [v for _, k, g, c, v in fetch if c == "FETCH_SIZE" and "query_kernel" in k]
+    qw = [v for _, k, g, c, v in write if c == "WRITE_SIZE" and "query_kernel" in k]
+    qname = next((k for _, k, g, c, v in fetch if "query_kernel" in k), None)
+    if qf and qw:
+        fb, wb = qf[-1] * 1024.0, qw[-1] * 1024.0
+        j = {"kernel": qname, "n_chars": n_chars, "queries": queries,
+             "workload": f"bench.py default: one batch of {queries:,} 16-byte patterns over the N={n_chars:,} index (50 % text windows, 50 % random)",
+             "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "traffic_bytes_per_launch": fb + wb,
+             "bytes_per_query": (fb + wb) / queries,
+             "corrections": "FETCH_SIZE x1: a random narrow read is ONE 64-byte request and is tallied exactly (tools/gatherbench: 16.8 M random "
+                            "4-byte reads of a 4 GiB table = 16.76 M requests = 64.0 B per read by FETCH_SIZE; no 32-byte, no 128-byte requests); "
+                            "WRITE_SIZE exact; counters in KiB",
+             "commands": cmds, "source": tag}
+        rr = {c: v for _, k, g, c, v in raw if "query_kernel" in k}
+        if rr:
+            j["raw_requests"] = rr
+            j["read_requests_per_query"] = rr.get("TCC_EA0_RDREQ_sum", 0.0) / queries
+        json.dump(j, open(os.path.join(ROOT, "profiles", "pmc_query.json"), "w"), indent=1)
+        print(json.dumps(j, indent=1))
+
+    # ---- calibration on random reads ------------------------------------------------------------------------------------
+    cf, cr = rows(counter_file(tag, "calib_fetch")), rows(counter_file(tag, "calib_raw"))
+    if cf:
+        reads = 1 << 24
+        lines = [f"# FETCH_SIZE on random narrow reads ({tag})", "",
+                 "`rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- tools/gatherbench` and the same with",
+                 "`--pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum`: 2^24 lanes read one element each at a hashed index of a",
+                 "4 GiB table (every read a distinct sector, far beyond the 256 MiB Infinity Cache).", "",
+                 "| kernel | counter | per dispatch | per read |", "|---|---|---|---|"]
+        for _, k, g, c, v in cf + cr:
+            if "gather_kernel" in k:
+                per = v * 1024.0 / reads if c == "FETCH_SIZE" else v / reads
+                lines.append(f"| `{k}` | {c} | {v:.1f}{' KiB' if c == 'FETCH_SIZE' else ''} | {per:.3f}{' B' if c == 'FETCH_SIZE' else ' requests'} |")
+        lines += ["", "A random 4- or 8-byte read leaves the L2 as ONE 64-byte request and FETCH_SIZE tallies exactly those 64 bytes: no x2",
+                  "correction for `query_kernel` (the x2 of the streaming kernels comes from their 128-byte requests being tallied at 64).",
+                  "Rate of the same kernel without the profiler (`tools/gatherbench`): 35-36 G random reads/s = 2.3 TB/s of 64-byte",
+                  "sectors -- the request-rate ceiling of the memory system for this access pattern."]
+        open(os.path.join(ROOT, "profiles", f"{tag}_pmc_calibration.md"), "w").write("\n".join(lines) + "\n")
+        print("\n".join(lines))
 
 
 if __name__ == "__main__":
