@@ -188,6 +188,10 @@ typedef struct sa_hip_build_stats {
     uint32_t text_top_pass;      /* 1: kernel [1] was text_top_pass_kernel<512> (keys assembled from the text) */
     uint32_t narrow_k;           /* 1: the index keeps u32 narrow keys + 257 bucket bounds as its query key array   */
     double   widen_ms;           /* HIP-event time of the last sa_hip_index_widen_device after this build (0: none)  */
+    uint64_t finisher_records;   /* records of groups that fit a tile, summed over the runs of the in-LDS group finisher */
+    uint64_t finisher_resolved;  /* suffixes it ordered finally (they never see a global refinement round)            */
+    uint32_t finisher_runs;
+    uint32_t reserved0;
 } sa_hip_build_stats;
 int sa_hip_index_build_stats(const sa_hip_index* idx, sa_hip_build_stats* out);
 

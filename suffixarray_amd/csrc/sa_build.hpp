@@ -25,6 +25,7 @@
 #include "common.hpp"
 #include "radix_narrow.hpp"
 #include "round_sort.hpp"
+#include "group_finish.hpp"
 
 namespace sa {
 
@@ -942,6 +943,10 @@ struct Builder {
     bool tiny_finisher = true;        // SA_HIP_TINY: direct-comparison finisher for groups of <= 8
     bool local_rounds = true;         // SA_HIP_LOCAL_ROUNDS: rounds sorted group-wise in LDS (round_sort.hpp)
     DevBuf gstart, loc_tiles, big_keys, big_vals;
+    bool group_finish = true;         // SA_HIP_GROUP_FINISH: groups that fit a tile are refined to the end in LDS (group_finish.hpp)
+    bool fin_useful = true;           // per build: cleared when a run resolves less than a quarter of what it looked at
+    bool use_pilot = true;            // SA_HIP_PILOT: 0 = initial key length from the byte distribution alone
+    DevBuf fin_flag;                  // u8[M]: per list position, final / head marks of the finisher
     u64 local_records = 0, big_records = 0;   // of the last build: records sorted in LDS / through the big-group list
     LocTile one_tile{};                       // source of an asynchronous copy (round_sort, lists of at most one tile)
     bool debug_rounds = false;
@@ -1008,6 +1013,8 @@ struct Builder {
         if (const char* e = getenv("SA_HIP_NARROW_K")) narrow_k = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_TINY")) tiny_finisher = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_LOCAL_ROUNDS")) local_rounds = atoi(e) != 0;
+        if (const char* e = getenv("SA_HIP_GROUP_FINISH")) group_finish = atoi(e) != 0;
+        if (const char* e = getenv("SA_HIP_PILOT")) use_pilot = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_DEBUG_ROUNDS")) debug_rounds = atoi(e) != 0;
         if (debug_rounds) { radix.debug_hook = &Builder::sort_debug_hook; radix.debug_ctx = this; }
         if ((rc = radix.init(cap, sort_block))) return rc;
@@ -1032,7 +1039,7 @@ struct Builder {
     void destroy() {
         DevBuf* all[] = {&text, &keys0, &keys1, &vals0, &vals1, &flags, &counts, &small, &isa, &apos0, &apos1, &aidx,
                          &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir, &dbg, &done, &pilot,
-                         &gstart, &loc_tiles, &big_keys, &big_vals};
+                         &gstart, &loc_tiles, &big_keys, &big_vals, &fin_flag};
         for (DevBuf* b : all) b->release();
         radix.destroy();
         narrow.destroy();
@@ -1052,7 +1059,7 @@ struct Builder {
         // pilot (independent of the histogram: raw bytes), only for texts large enough to matter
         u32 pilot_dups = 0;
         pilot_dup_share = 0.0;
-        const bool run_pilot = n >= (u64)16 * PILOT_SAMPLES;
+        const bool run_pilot = use_pilot && n >= (u64)16 * PILOT_SAMPLES;
         if (run_pilot) {
             int rc = pilot.ensure((size_t)PILOT_SLOTS * 8 + 64);
             if (rc) return rc;
@@ -1328,13 +1335,13 @@ struct Builder {
             if ((rc = big_keys.ensure((size_t)big * 8))) return rc;
             if ((rc = big_vals.ensure((size_t)big * 4))) return rc;
             const u32 cg = ntiles < 2048u ? ntiles : 2048u;
-            hipLaunchKernelGGL(loc_big_copy_kernel, dim3(cg), dim3(256), 0, stream, (const LocTile*)loc_tiles.as<LocTile>(), ntiles, true,
+            hipLaunchKernelGGL(loc_big_copy_kernel, dim3(cg, 16), dim3(256), 0, stream, (const LocTile*)loc_tiles.as<LocTile>(), ntiles, true,
                                k0, const_cast<u32*>(vsrc), big_keys.as<u64>(), big_vals.as<u32>());
             // (k0, v0) are free from here on: the partner buffers of the list's ping-pong
             u64* rk; u32* rv;
             if ((rc = radix_sort_pairs(radix, stream, big_keys.as<u64>(), big_vals.as<u32>(), k0, v0, big, begin_bit, end_bit, false,
                                        false, &rk, &rv))) return rc;
-            hipLaunchKernelGGL(loc_big_copy_kernel, dim3(cg), dim3(256), 0, stream, (const LocTile*)loc_tiles.as<LocTile>(), ntiles, false,
+            hipLaunchKernelGGL(loc_big_copy_kernel, dim3(cg, 16), dim3(256), 0, stream, (const LocTile*)loc_tiles.as<LocTile>(), ntiles, false,
                                k1, v1, rk, rv);
         }
         SA_HIP_CHECK(hipGetLastError());
@@ -1343,11 +1350,65 @@ struct Builder {
         return 0;
     }
 
+    // Groups that fit a tile are refined to the end in LDS (group_finish.hpp); what it resolves leaves the active list.
+    // In: the active list (apos_cur, aidx, gid) of M records in G groups at depth h.  Out: M, G, the lists compacted.
+    int run_group_finisher(const CodeMap& map, int b, u32 L, u64 h, u32& M, u32& G, u32*& apos_cur, u32*& apos_nxt, u32* tot) {
+        int rc;
+        u32 ntiles = div_up(M, LOC_TILE);
+        if ((rc = gstart.ensure(((size_t)G + 2) * 4))) return rc;
+        if ((rc = loc_tiles.ensure((size_t)ntiles * sizeof(LocTile) + 64))) return rc;
+        if ((rc = done.ensure((size_t)M + 64))) return rc;
+        if ((rc = fin_flag.ensure((size_t)M + 64))) return rc;
+        if (M <= LOC_CAP) {
+            one_tile.begin = 0; one_tile.local_end = M; one_tile.end = M; one_tile.big_off = 0;
+            SA_HIP_CHECK(hipMemcpyAsync(loc_tiles.p, &one_tile, sizeof one_tile, hipMemcpyHostToDevice, stream));
+            ntiles = 1;
+        } else {
+            hipLaunchKernelGGL(group_starts_kernel, dim3(stream_grid(M, 1024)), dim3(256), 0, stream, gid.as<u32>(), M, G, gstart.as<u32>());
+            hipLaunchKernelGGL(loc_plan_kernel, dim3(div_up(ntiles, 256)), dim3(256), 0, stream, gid.as<u32>(), gstart.as<u32>(), M, ntiles,
+                               loc_tiles.as<LocTile>());
+        }
+        unsigned long long* ft = reinterpret_cast<unsigned long long*>(small.as<u8>() + 3640);
+        SA_HIP_CHECK(hipMemsetAsync(ft, 0, 16, stream));
+        SA_HIP_CHECK(hipMemsetAsync(done.p, 0, (size_t)M, stream));   // records of groups too large for a tile stay untouched
+        FinArgs a;
+        a.text = text.as<u8>(); a.n = n; a.b = b;
+        a.aidx = aidx.as<u32>(); a.gid = gid.as<u32>(); a.apos = apos_cur; a.tiles = loc_tiles.as<LocTile>();
+        a.h0 = (u32)h; a.L = L; a.max_rounds = FIN_MAX_ROUNDS;
+        a.sa = sa; a.gflags = flags.as<u8>(); a.done = done.as<u8>();
+        a.res_idx = ridx0.as<u32>(); a.res_fin = fin_flag.as<u8>(); a.totals = ft;
+        hipLaunchKernelGGL(group_finish_kernel, dim3(ntiles), dim3(FIN_BLOCK), 0, stream, a, map);
+        unsigned long long ft_host[2] = {0, 0};
+        SA_HIP_CHECK(hipMemcpyAsync(ft_host, ft, 16, hipMemcpyDeviceToHost, stream));
+        const u32 tiles = div_up(M, BLD_TILE);
+        hipLaunchKernelGGL(tiny_flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, gid.as<u32>(), done.as<u8>(), M, lf.as<u8>(),
+                           counts.as<uint2>());
+        if ((rc = scan_counts(tiles, tot))) return rc;   // synchronises: ft_host is valid
+        stats.finisher_runs += 1;
+        stats.finisher_records += ft_host[0];
+        stats.finisher_resolved += (u64)M - tot[0];
+        if (ft_host[1] * 4 < ft_host[0]) fin_useful = false;   // long repeats: leave them to the doubling rounds
+        if (debug_rounds)
+            fprintf(stderr, "[sa_hip] finisher h=%llu M=%u G=%u tiles=%u: looked at %llu, resolved %llu -> M'=%u G'=%u\n", (unsigned long long)h, M, G,
+                    ntiles, ft_host[0], ft_host[1], tot[0], tot[1]);
+        if (tot[0] < M) {
+            if (tot[0]) {
+                SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
+                launch_compact(lf.as<u8>(), M, tot[0], apos_cur, ridx0.as<u32>(), apos_nxt, aidx.as<u32>(), gid.as<u32>());
+                u32* t = apos_cur; apos_cur = apos_nxt; apos_nxt = t;
+            }
+            M = tot[0];
+            G = tot[1];
+        }
+        return 0;
+    }
+
     // The device build.  Text already resident in text.p[0..n_).
     int build(u64 n_, u32 L) {
         int rc;
         memset(&stats, 0, sizeof stats);
         local_records = big_records = 0;
+        fin_useful = true;
         radix.reset_stats();
         max_suffix_length = L;
         stats.n = n_;
@@ -1468,6 +1529,12 @@ struct Builder {
 
         u32 M_prev = 0;   // active-set size of the previous round (0: none yet)
         while (M && (L == 0 || h < L)) {
+            // groups that fit a tile are finished in LDS, whatever their number of rounds; the global round below is for
+            // the rest (an average group of more than half a tile: hardly anything fits)
+            if (group_finish && fin_useful && !have_isa && (u64)M <= (u64)G * (LOC_CAP / 2)) {
+                if ((rc = run_group_finisher(map, b, L, h, M, G, apos_cur, apos_nxt, tot))) return rc;
+                if (!M) break;
+            }
             const int gb = bits_for(G);
             // Chunk rounds read the next characters from the text; doubling rounds need the inverse suffix array
             // (one random 4-byte write per suffix of the WHOLE text the first time) and pay off only on long

@@ -170,6 +170,7 @@ def test_rounds_sorted_in_lds_match_global_sort(gpu, oracle, monkeypatch):
     blk = np.tile(rng.integers(97, 101, 200_000, dtype=np.uint8), 12)
     runs = [("words", words, 0), ("words_L20", words, 20), ("run", run, 0), ("skew", skew, 0), ("blocks", blk, 0),
             ("d2_300k", cases.small_texts()["d2_300k"], 0), ("repeat_block", cases.small_texts()["repeat_block"], 0)]
+    monkeypatch.setenv("SA_HIP_GROUP_FINISH", "0")   # every group through the rounds (the finisher has its own test below)
     for name, t, L in runs:
         got, stats = {}, {}
         for mode in ("1", "0"):
@@ -229,3 +230,57 @@ def test_widen_device_is_the_libsais64_layout(gpu, oracle):
                 assert np.array_equal(got[:tt.size], oracle.sais(tt).astype(np.int64)), (name, cut)
                 assert (got[tt.size:] == -7).all()
                 assert idx.build_stats()["widen_ms"] >= 0.0
+
+
+def test_group_finisher_matches_global_rounds(gpu, oracle, monkeypatch):
+    """Groups that fit a tile are refined to the end by one workgroup in LDS (group_finish.hpp: fetch characters, stable
+    radix sort by (group, characters), split, drop singletons, until nothing is tied; deferred writes; groups it cannot
+    finish -- larger than a tile, or still tied after its round limit -- stay on the global path untouched).  Same suffix
+    array as with SA_HIP_GROUP_FINISH=0, verified on the device and against the oracle: word text at several
+    truncation depths (the finisher stops at depth L, ties in text order), short initial keys (dense active set, groups
+    of every size), a 60 000-character run (one group far larger than a tile), blocks repeated 12 times (groups of 12
+    that no bounded number of rounds separates: the finisher must give up and leave them to the doubling rounds), a
+    skewed alphabet, near-random text without the tiny-group finisher (pairs), texts that end inside a group."""
+    from suffixarray_amd import synth
+    rng = np.random.default_rng(77)
+    words = synth.d2_words(5_000_000)
+    run = synth.d2_words(3_000_000).copy()
+    run[1_000_000:1_060_000] = ord("q")
+    skew = rng.choice(np.array([97, 98, 99, 100, 122], dtype=np.uint8), 3_000_000, p=[0.9, 0.04, 0.03, 0.02, 0.01])
+    blk = np.tile(rng.integers(97, 101, 200_000, dtype=np.uint8), 12)
+    tail = np.concatenate([synth.d2_words(400_000), np.frombuffer(b"abcabcabcabcabcabcabcabcabcabcabcabcabc" * 50, np.uint8)])
+    st = cases.small_texts()
+    runs = [("words", words, 0, {}), ("words_L1", words, 1, {}), ("words_L9", words, 9, {}), ("words_L20", words, 20, {}),
+            ("words_L33", words, 33, {}), ("words_k4", words, 0, {"SA_HIP_INITIAL_CHARS": "4"}),
+            ("words_nopilot", words, 0, {"SA_HIP_PILOT": "0"}), ("words_nopilot_L32", words, 32, {"SA_HIP_PILOT": "0"}),
+            ("run", run, 0, {}), ("skew", skew, 0, {}), ("skew_L7", skew, 7, {}), ("blocks", blk, 0, {}), ("tail", tail, 0, {}),
+            ("d1_pairs", synth.d1_uniform27(4_500_000), 0, {"SA_HIP_TINY": "0"}),
+            ("d1_pairs_L10", synth.d1_uniform27(4_500_000), 10, {"SA_HIP_TINY": "0"}),
+            ("d2_300k", st["d2_300k"], 0, {}), ("repeat_block", st["repeat_block"], 0, {}), ("fib", st["fib"], 0, {}),
+            ("all_a_70000", st["all_a_70000"], 0, {}), ("period7", st["period7"], 0, {}), ("r2_30000", st["r2_30000"], 0, {}),
+            ("with_nul", st["with_nul"], 0, {}), ("highbit", st["highbit"], 0, {})]
+    for name, t, L, env in runs:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got, stats = {}, {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SA_HIP_GROUP_FINISH", mode)
+            with gpu.DeviceIndex(t.size, 0) as idx:
+                idx.build(t, L)
+                stats[mode] = idx.build_stats()
+                assert idx.verify() == 0, (name, mode, stats[mode])
+                got[mode] = idx.sa_u32().copy()
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        assert np.array_equal(got["1"], got["0"]), (name, stats)
+        assert stats["0"]["finisher_runs"] == 0
+        if name.startswith("words") and L not in (1, 9):   # (L <= the initial key length: nothing to refine)
+            assert stats["1"]["finisher_resolved"] > 0 and stats["1"]["active_total"] < stats["0"]["active_total"], (name, stats)
+        if name in ("d1_pairs", "d1_pairs_L10"):
+            assert stats["1"]["finisher_resolved"] > 0 and stats["1"]["rounds"] == 0, (name, stats["1"])
+        if name == "blocks":   # nothing to finish: groups of 12 with common prefixes of 200 000 characters
+            assert stats["1"]["finisher_resolved"] < blk.size // 100 and stats["1"]["doubling_rounds"] > 0, stats["1"]
+        if L == 0 and t.size <= 5_000_000:
+            assert np.array_equal(got["1"], oracle.sais(t).astype(np.uint32)), name
+        elif L:
+            assert np.array_equal(got["1"], oracle.truncated_sa(t, L)), name
