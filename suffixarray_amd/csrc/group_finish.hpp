@@ -25,15 +25,26 @@
 
 namespace sa {
 
-#ifndef SA_FIN_BLOCK
-#define SA_FIN_BLOCK 512
+// Tile capacity and workgroup size (LDS per tile = 18 bytes per record of capacity + the wave histograms).  Measured on
+// words / names 1e8 (tools/gpu_fin_sweep2.py): 4096 x 8 per thread (512 threads, two workgroups per CU) and 2048 x 8 (256
+// threads, four per CU) run alike -- 11.5 vs 11.6 ms, 7.8 vs 7.9 ms: the kernel is bound by its random text fetches (about
+// 1.25 per record it looks at, each a 64-byte sector), not by occupancy -- and the larger tile keeps more groups off the
+// global path; 4 records per thread (twice the barriers per record): +20 %, 16 per thread: +15 %.
+#ifndef SA_FIN_CAP
+#define SA_FIN_CAP 4096
 #endif
-constexpr int FIN_BLOCK = SA_FIN_BLOCK;                 // 512 threads x 8 records, or 256 x 16
-constexpr int FIN_ITEMS = (int)(LOC_CAP / FIN_BLOCK);
-constexpr int FIN_POS_BITS = LOC_GID_BITS;              // a record's index in the tile: 12 bits
+#ifndef SA_FIN_ITEMS
+#define SA_FIN_ITEMS 8
+#endif
+constexpr u32 FIN_CAP = SA_FIN_CAP;                     // records per tile (power of two)
+constexpr int FIN_ITEMS = SA_FIN_ITEMS;                 // records per thread
+constexpr int FIN_BLOCK = (int)(FIN_CAP / FIN_ITEMS);
+constexpr u32 FIN_TILE = FIN_CAP - FIN_CAP / 8;         // nominal tile length (round_sort.hpp: tiles of whole groups)
+constexpr int fin_log2(u32 v) { return v <= 1 ? 0 : 1 + fin_log2(v >> 1); }
+constexpr int FIN_POS_BITS = fin_log2(FIN_CAP);         // a record's index in the tile
 constexpr u32 FIN_MAX_ROUNDS = 24;
-static_assert(FIN_BLOCK * FIN_ITEMS == (int)LOC_CAP && FIN_ITEMS % 2 == 0, "tile = LOC_CAP records");
-static_assert((FIN_BLOCK / WAVE) * FIN_ITEMS == 64, "one lane per row in the compaction scan");
+static_assert((1u << FIN_POS_BITS) == FIN_CAP && FIN_ITEMS % 2 == 0 && FIN_BLOCK % WAVE == 0 && FIN_BLOCK >= RADIX, "tile geometry");
+static_assert((FIN_BLOCK / WAVE) * FIN_ITEMS <= 64, "at most one lane per row in the compaction scan");
 
 struct FinArgs {
     const u8* text;
@@ -42,16 +53,20 @@ struct FinArgs {
     const u32* aidx;       // active list: suffix index
     const u32* gid;        //              dense group id (ascending)
     const u32* apos;       //              SA slot
-    const LocTile* tiles;  // records [begin, local_end) of tile t are whole groups, at most LOC_CAP of them
+    const LocTile* tiles;  // records [begin, local_end) of tile t are whole groups, at most FIN_CAP of them
     u32 h0;                // characters every group is known to share
     u32 L;                 // truncated build: order by the first L characters only (0 = full)
     u32 max_rounds;
+    u32 count_max;         // a round whose largest group has at most this many records is ordered by counting
+    int radix_chars;       // characters per round while larger groups exist (radix rounds; 0 = as many as fit)
     u32* sa;               // out: suffix array slots of resolved groups
     u8* gflags;            // out: bit0 = group head, per SA slot
     u8* done;              // out: per list element 1 = final (its group was resolved and written), 0 = untouched
     u32* res_idx;          // scratch [M]: final suffix per list position
     u8* res_fin;           // scratch [M]: 0 not final, 1 final, 3 final + head of a (sub)group
-    unsigned long long* totals;   // [0] records in tiles, [1] records resolved
+    unsigned long long* totals;   // [0] records in tiles, [1] records resolved; debug: [2] rounds, [3] radix rounds,
+                                  // [4] record slots of the radix rounds, [5] of the counting rounds, [6] tiles, [7] active records over all rounds
+    int debug;
 };
 
 __device__ __forceinline__ int fin_bits_for(u32 count) {   // smallest g with 2^g >= count
@@ -99,12 +114,13 @@ __device__ __forceinline__ void fin_wave_rank(const u64 (&key)[ITEMS], int shift
 
 // groups of at most FIN_COUNT_MAX records are ordered by counting (rank = members with a smaller key) instead of radix
 // passes: for the typical handful of members that is a few dozen instructions per record against ~280 for seven passes
-constexpr u32 FIN_COUNT_MAX = 48;
+constexpr u32 FIN_COUNT_MAX = 96;   // 0 / 48 / 96 / 160: words 1e8 11.5 / 11.0 / 10.8 / 10.9 ms
+constexpr int FIN_RADIX_CHARS = 0;
 
 __global__ __launch_bounds__(FIN_BLOCK) void group_finish_kernel(FinArgs a, CodeMap map) {
     constexpr int WAVES = FIN_BLOCK / WAVE;
     constexpr int ITEMS = FIN_ITEMS;
-    constexpr u32 CAP = LOC_CAP;
+    constexpr u32 CAP = FIN_CAP;
     __shared__ u64 s_key[CAP];
     __shared__ u32 s_idx[CAP];          // by compact index: suffix
     __shared__ u16 s_lgid[CAP];         // by compact index: dense id of the record's group among the active groups
@@ -138,6 +154,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void group_finish_kernel(FinArgs a, Code
     __syncthreads();
 
     u32 h = a.h0, rounds = 0, stall = 0;
+    u32 dbg_radix = 0, dbg_slots_r = 0, dbg_slots_c = 0, dbg_act = 0;
     u32* wh = s_whist + wave * RADIX;
     while (true) {
         const u32 A = s_A, G = s_G;
@@ -164,9 +181,14 @@ __global__ __launch_bounds__(FIN_BLOCK) void group_finish_kernel(FinArgs a, Code
             for (int o = 32; o > 0; o >>= 1) { const u32 t = __shfl_down(mx, o); mx = t > mx ? t : mx; }
             if (lane == 0 && mx) atomicMax(&s_maxg, mx);
         }
+        sync_lds();   // s_maxg complete (LDS atomics above)
+        const bool counting = s_maxg <= a.count_max;
+        if (counting) dbg_slots_c += (u32)(WAVE * WAVES * R); else { dbg_slots_r += (u32)(WAVE * WAVES * R); ++dbg_radix; }
+        dbg_act += A;
         const int gbits = fin_bits_for(G);
         int kc = (64 - FIN_POS_BITS - gbits) / a.b;
         if (kc > 8) kc = 8;
+        if (!counting && a.radix_chars > 0 && kc > a.radix_chars) kc = a.radix_chars;   // cheap rounds until the large groups are apart
         if (a.L && (u32)kc > a.L - h) kc = (int)(a.L - h);   // h < L while anything is active
         const int cbits = kc * a.b;
         const bool last_trunc = a.L && (h + (u32)kc >= a.L);
@@ -196,8 +218,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void group_finish_kernel(FinArgs a, Code
                 }
             }
         }
-        sync_lds();   // s_maxg complete (LDS atomics above)
-        if (s_maxg <= FIN_COUNT_MAX) {
+        if (counting) {
             // 2a. every group is small: a record's place inside its group = the members with a smaller key (the keys are
             //     distinct: they end in the compact index, which also makes the order stable)
 #pragma unroll
@@ -356,7 +377,14 @@ __global__ __launch_bounds__(FIN_BLOCK) void group_finish_kernel(FinArgs a, Code
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) resolved += __shfl_down(resolved, o);
     if (lane == 0 && resolved) atomicAdd(&a.totals[1], (unsigned long long)resolved);
-    if (tid == 0) atomicAdd(&a.totals[0], (unsigned long long)cnt);
+    if (tid == 0) {
+        atomicAdd(&a.totals[0], (unsigned long long)cnt);
+        if (a.debug) {
+            atomicAdd(&a.totals[2], (unsigned long long)rounds); atomicAdd(&a.totals[3], (unsigned long long)dbg_radix);
+            atomicAdd(&a.totals[4], (unsigned long long)dbg_slots_r); atomicAdd(&a.totals[5], (unsigned long long)dbg_slots_c);
+            atomicAdd(&a.totals[6], 1ull); atomicAdd(&a.totals[7], (unsigned long long)dbg_act);
+        }
+    }
 }
 
 }  // namespace sa

@@ -54,27 +54,31 @@ struct LocTile {
     u32 big_off;     // exclusive prefix of (end - local_end) over the tiles, filled by loc_scan_kernel
 };
 
+template <u32 TILE>
 __device__ __forceinline__ u32 loc_tile_start(const u32* gid, const u32* gstart, u32 m_count, u64 t) {
-    const u64 p = t * LOC_TILE;
+    const u64 p = t * TILE;
     if (p >= m_count) return m_count;
     const u32 g = gid[p];
     return (gstart[g] == (u32)p) ? (u32)p : gstart[g + 1];   // p inside a group: that group belongs to the tile before
 }
 
+// TILE = nominal tile length, CAP = what a workgroup can hold (the tile-local round sort: LOC_TILE, LOC_CAP; the group
+// finisher has its own pair, group_finish.hpp)
+template <u32 TILE = LOC_TILE, u32 CAP = LOC_CAP>
 __global__ __launch_bounds__(256) void loc_plan_kernel(const u32* __restrict__ gid, const u32* __restrict__ gstart, u32 m_count,
                                                        u32 ntiles, LocTile* __restrict__ tiles) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
-    const u32 a = loc_tile_start(gid, gstart, m_count, t);
-    const u32 b = loc_tile_start(gid, gstart, m_count, (u64)t + 1);
+    const u32 a = loc_tile_start<TILE>(gid, gstart, m_count, t);
+    const u32 b = loc_tile_start<TILE>(gid, gstart, m_count, (u64)t + 1);
     LocTile lt;
     lt.begin = a;
     lt.end = b < a ? a : b;
     lt.local_end = lt.end;
-    if (lt.end - a > LOC_CAP) {
+    if (lt.end - a > CAP) {
         // the group that straddles (t+1)*T makes the tile too long: everything before it fits (it starts before
         // (t+1)*T, so [a, its start) has fewer than T records)
-        lt.local_end = gstart[gid[(u64)(t + 1) * LOC_TILE]];
+        lt.local_end = gstart[gid[(u64)(t + 1) * TILE]];
     }
     lt.big_off = 0;
     tiles[t] = lt;

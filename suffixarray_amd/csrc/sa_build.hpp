@@ -947,6 +947,8 @@ struct Builder {
     bool fin_useful = true;           // per build: cleared when a run resolves less than a quarter of what it looked at
     bool use_pilot = true;            // SA_HIP_PILOT: 0 = initial key length from the byte distribution alone
     DevBuf fin_flag;                  // u8[M]: per list position, final / head marks of the finisher
+    u32 fin_count_max = FIN_COUNT_MAX;   // SA_HIP_FIN_COUNT_MAX
+    int fin_radix_chars = FIN_RADIX_CHARS;   // SA_HIP_FIN_RADIX_CHARS
     u64 local_records = 0, big_records = 0;   // of the last build: records sorted in LDS / through the big-group list
     LocTile one_tile{};                       // source of an asynchronous copy (round_sort, lists of at most one tile)
     bool debug_rounds = false;
@@ -1015,6 +1017,8 @@ struct Builder {
         if (const char* e = getenv("SA_HIP_LOCAL_ROUNDS")) local_rounds = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_GROUP_FINISH")) group_finish = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_PILOT")) use_pilot = atoi(e) != 0;
+        if (const char* e = getenv("SA_HIP_FIN_COUNT_MAX")) fin_count_max = (u32)atoi(e);
+        if (const char* e = getenv("SA_HIP_FIN_RADIX_CHARS")) fin_radix_chars = atoi(e);
         if (const char* e = getenv("SA_HIP_DEBUG_ROUNDS")) debug_rounds = atoi(e) != 0;
         if (debug_rounds) { radix.debug_hook = &Builder::sort_debug_hook; radix.debug_ctx = this; }
         if ((rc = radix.init(cap, sort_block))) return rc;
@@ -1315,7 +1319,7 @@ struct Builder {
             ntiles = 1;
         } else {
         hipLaunchKernelGGL(group_starts_kernel, dim3(stream_grid(M, 1024)), dim3(256), 0, stream, gid.as<u32>(), M, G, gstart.as<u32>());
-        hipLaunchKernelGGL(loc_plan_kernel, dim3(div_up(ntiles, 256)), dim3(256), 0, stream, gid.as<u32>(), gstart.as<u32>(), M, ntiles,
+        hipLaunchKernelGGL((loc_plan_kernel<LOC_TILE, LOC_CAP>), dim3(div_up(ntiles, 256)), dim3(256), 0, stream, gid.as<u32>(), gstart.as<u32>(), M, ntiles,
                            loc_tiles.as<LocTile>());
         hipLaunchKernelGGL(loc_scan_kernel, dim3(1), dim3(1024), 0, stream, loc_tiles.as<LocTile>(), ntiles, total_dev);
         SA_HIP_CHECK(hipMemcpyAsync(&big, total_dev, 4, hipMemcpyDeviceToHost, stream));
@@ -1354,32 +1358,33 @@ struct Builder {
     // In: the active list (apos_cur, aidx, gid) of M records in G groups at depth h.  Out: M, G, the lists compacted.
     int run_group_finisher(const CodeMap& map, int b, u32 L, u64 h, u32& M, u32& G, u32*& apos_cur, u32*& apos_nxt, u32* tot) {
         int rc;
-        u32 ntiles = div_up(M, LOC_TILE);
+        u32 ntiles = div_up(M, FIN_TILE);
         if ((rc = gstart.ensure(((size_t)G + 2) * 4))) return rc;
         if ((rc = loc_tiles.ensure((size_t)ntiles * sizeof(LocTile) + 64))) return rc;
         if ((rc = done.ensure((size_t)M + 64))) return rc;
         if ((rc = fin_flag.ensure((size_t)M + 64))) return rc;
-        if (M <= LOC_CAP) {
+        if (M <= FIN_CAP) {
             one_tile.begin = 0; one_tile.local_end = M; one_tile.end = M; one_tile.big_off = 0;
             SA_HIP_CHECK(hipMemcpyAsync(loc_tiles.p, &one_tile, sizeof one_tile, hipMemcpyHostToDevice, stream));
             ntiles = 1;
         } else {
             hipLaunchKernelGGL(group_starts_kernel, dim3(stream_grid(M, 1024)), dim3(256), 0, stream, gid.as<u32>(), M, G, gstart.as<u32>());
-            hipLaunchKernelGGL(loc_plan_kernel, dim3(div_up(ntiles, 256)), dim3(256), 0, stream, gid.as<u32>(), gstart.as<u32>(), M, ntiles,
-                               loc_tiles.as<LocTile>());
+            hipLaunchKernelGGL((loc_plan_kernel<FIN_TILE, FIN_CAP>), dim3(div_up(ntiles, 256)), dim3(256), 0, stream, gid.as<u32>(), gstart.as<u32>(), M,
+                               ntiles, loc_tiles.as<LocTile>());
         }
         unsigned long long* ft = reinterpret_cast<unsigned long long*>(small.as<u8>() + 3640);
-        SA_HIP_CHECK(hipMemsetAsync(ft, 0, 16, stream));
+        SA_HIP_CHECK(hipMemsetAsync(ft, 0, 64, stream));
         SA_HIP_CHECK(hipMemsetAsync(done.p, 0, (size_t)M, stream));   // records of groups too large for a tile stay untouched
         FinArgs a;
         a.text = text.as<u8>(); a.n = n; a.b = b;
         a.aidx = aidx.as<u32>(); a.gid = gid.as<u32>(); a.apos = apos_cur; a.tiles = loc_tiles.as<LocTile>();
         a.h0 = (u32)h; a.L = L; a.max_rounds = FIN_MAX_ROUNDS;
+        a.count_max = fin_count_max; a.radix_chars = fin_radix_chars; a.debug = debug_rounds ? 1 : 0;
         a.sa = sa; a.gflags = flags.as<u8>(); a.done = done.as<u8>();
         a.res_idx = ridx0.as<u32>(); a.res_fin = fin_flag.as<u8>(); a.totals = ft;
         hipLaunchKernelGGL(group_finish_kernel, dim3(ntiles), dim3(FIN_BLOCK), 0, stream, a, map);
-        unsigned long long ft_host[2] = {0, 0};
-        SA_HIP_CHECK(hipMemcpyAsync(ft_host, ft, 16, hipMemcpyDeviceToHost, stream));
+        unsigned long long ft_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        SA_HIP_CHECK(hipMemcpyAsync(ft_host, ft, 64, hipMemcpyDeviceToHost, stream));
         const u32 tiles = div_up(M, BLD_TILE);
         hipLaunchKernelGGL(tiny_flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, gid.as<u32>(), done.as<u8>(), M, lf.as<u8>(),
                            counts.as<uint2>());
@@ -1389,8 +1394,9 @@ struct Builder {
         stats.finisher_resolved += (u64)M - tot[0];
         if (ft_host[1] * 4 < ft_host[0]) fin_useful = false;   // long repeats: leave them to the doubling rounds
         if (debug_rounds)
-            fprintf(stderr, "[sa_hip] finisher h=%llu M=%u G=%u tiles=%u: looked at %llu, resolved %llu -> M'=%u G'=%u\n", (unsigned long long)h, M, G,
-                    ntiles, ft_host[0], ft_host[1], tot[0], tot[1]);
+            fprintf(stderr, "[sa_hip] finisher h=%llu M=%u G=%u tiles=%u (%llu non-empty): looked at %llu, resolved %llu -> M'=%u G'=%u; rounds %llu (%llu radix), "
+                    "slots radix %llu counting %llu, active record-rounds %llu\n", (unsigned long long)h, M, G, ntiles, ft_host[6], ft_host[0], ft_host[1],
+                    tot[0], tot[1], ft_host[2], ft_host[3], ft_host[4], ft_host[5], ft_host[7]);
         if (tot[0] < M) {
             if (tot[0]) {
                 SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
@@ -1531,7 +1537,7 @@ struct Builder {
         while (M && (L == 0 || h < L)) {
             // groups that fit a tile are finished in LDS, whatever their number of rounds; the global round below is for
             // the rest (an average group of more than half a tile: hardly anything fits)
-            if (group_finish && fin_useful && !have_isa && (u64)M <= (u64)G * (LOC_CAP / 2)) {
+            if (group_finish && fin_useful && !have_isa && (u64)M <= (u64)G * (FIN_CAP / 2)) {
                 if ((rc = run_group_finisher(map, b, L, h, M, G, apos_cur, apos_nxt, tot))) return rc;
                 if (!M) break;
             }
