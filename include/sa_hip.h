@@ -98,6 +98,12 @@ void sa_hip_index_destroy(sa_hip_index* idx);
 int sa_hip_index_build(sa_hip_index* idx, const uint8_t* T_host, uint64_t n, uint32_t max_suffix_length);
 /* Same, text already in device memory of idx's device (copied device-to-device into the index). */
 int sa_hip_index_build_device(sa_hip_index* idx, const void* T_dev, uint64_t n, uint32_t max_suffix_length);
+/* Build + libsais64 layout in one call (replaces libsais64 on device buffers, libsais64.c:6657-6685): as
+ * sa_hip_index_build_device, and sa64_dev[i] = (int64_t)SA[i] for i in [0, n), sa64_dev a device buffer of n * 8 bytes
+ * on the index's device.  The widening is not a pass of its own here: on the narrow-record plan the last pass of the
+ * sort stores every suffix index as u32 (the index's own array) and as int64 (sa64_dev), and the few slots refined
+ * afterwards are patched; other plans end with the widening kernel.  total_ms of the build statistics covers all of it. */
+int sa_hip_index_build_device64(sa_hip_index* idx, const void* T_dev, uint64_t n, uint32_t max_suffix_length, void* sa64_dev);
 /* Adopt an existing suffix array (host pointers): uploads T and SA and prepares the query
  * structures; SA must be sorted by the first max_suffix_length bytes (0 = fully sorted).
  * Every entry is range-checked on the device: an array with an entry >= n is refused (-1). */
@@ -191,7 +197,7 @@ typedef struct sa_hip_build_stats {
     uint64_t finisher_records;   /* records of groups that fit a tile, summed over the runs of the in-LDS group finisher */
     uint64_t finisher_resolved;  /* suffixes it ordered finally (they never see a global refinement round)            */
     uint32_t finisher_runs;
-    uint32_t reserved0;
+    uint32_t widen_fused;        /* 1: the int64 copy of sa_hip_index_build_device64 came out of the sort's last pass       */
 } sa_hip_build_stats;
 int sa_hip_index_build_stats(const sa_hip_index* idx, sa_hip_build_stats* out);
 

@@ -20,7 +20,7 @@ EXPORTS = [
     "sa_hip_libsais", "sa_hip_libsais_omp", "sa_hip_libsais64", "sa_hip_libsais64_omp",
     "sa_hip_construct_truncated_suffix_array", "sa_hip_get_substring_positions",
     "sa_hip_device_count", "sa_hip_index_create", "sa_hip_index_destroy", "sa_hip_index_build",
-    "sa_hip_index_build_device", "sa_hip_index_load", "sa_hip_index_load_device", "sa_hip_index_n",
+    "sa_hip_index_build_device", "sa_hip_index_build_device64", "sa_hip_index_load", "sa_hip_index_load_device", "sa_hip_index_n",
     "sa_hip_index_max_suffix_length", "sa_hip_index_text_dev", "sa_hip_index_sa_dev",
     "sa_hip_index_stream", "sa_hip_index_get_sa_u32", "sa_hip_index_get_sa_i64", "sa_hip_index_widen_device",
     "sa_hip_index_get_freq", "sa_hip_query_batch", "sa_hip_query_batch_device",
@@ -50,7 +50,7 @@ class BuildStats(C.Structure):
                 ("pass_ms", C.c_double * 4), ("pass_bytes", C.c_uint64 * 4), ("pass_launches", C.c_uint32 * 4),
                 ("text_top_pass", C.c_uint32), ("narrow_k", C.c_uint32), ("widen_ms", C.c_double),
                 ("finisher_records", C.c_uint64), ("finisher_resolved", C.c_uint64), ("finisher_runs", C.c_uint32),
-                ("reserved0", C.c_uint32)]
+                ("widen_fused", C.c_uint32)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if k.startswith("pass_") else getattr(self, k)) for k, _ in self._fields_}
@@ -107,6 +107,8 @@ def lib():
     L.sa_hip_index_build.argtypes = [vp, vp, u64, u32]
     L.sa_hip_index_build_device.restype = C.c_int
     L.sa_hip_index_build_device.argtypes = [vp, vp, u64, u32]
+    L.sa_hip_index_build_device64.restype = C.c_int
+    L.sa_hip_index_build_device64.argtypes = [vp, vp, u64, u32, vp]
     L.sa_hip_index_load.restype = C.c_int
     L.sa_hip_index_load.argtypes = [vp, vp, vp, u64, u32]
     L.sa_hip_index_load_device.restype = C.c_int
@@ -216,6 +218,11 @@ class DeviceIndex:
 
     def build_device(self, text_dev_ptr, n, max_suffix_length=0):
         check(self._lib.sa_hip_index_build_device(self._h, text_dev_ptr, n, max_suffix_length))
+        return self
+
+    def build_device64(self, text_dev_ptr, n, sa64_dev_ptr, max_suffix_length=0):
+        """Device build that also leaves the suffix array in libsais64 layout (int64[n]) in a device buffer."""
+        check(self._lib.sa_hip_index_build_device64(self._h, text_dev_ptr, n, max_suffix_length, sa64_dev_ptr))
         return self
 
     def load(self, text, sa, max_suffix_length=0):

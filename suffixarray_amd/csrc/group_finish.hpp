@@ -130,7 +130,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void group_finish_kernel(FinArgs a, Code
     __shared__ u32 s_wsum[RADIX / WAVE];
     __shared__ u32 s_rowa[64], s_rowh[64];
     __shared__ u32 s_fail[CAP / 32];    // original groups that were not resolved
-    __shared__ u8 s_map[256];
+    __shared__ u16 s_map[256];          // codes reach 256 when every byte value occurs (b = 9)
     __shared__ u32 s_A, s_G, s_maxg;
 
     const LocTile lt = a.tiles[blockIdx.x];
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void group_finish_kernel(FinArgs a, Code
     const u32 begin = lt.begin;
     const u32 gid0 = a.gid[begin];
 
-    if (tid < 256) s_map[tid] = (u8)map.code[tid];
+    if (tid < 256) s_map[tid] = map.code[tid];
     for (u32 i = tid; i < CAP / 32; i += FIN_BLOCK) s_fail[i] = 0;
     const u32 G0 = a.gid[begin + cnt - 1] - gid0 + 1;
     for (u32 p = tid; p < cnt; p += FIN_BLOCK) {

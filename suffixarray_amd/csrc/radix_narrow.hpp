@@ -162,6 +162,9 @@ struct SegPassArgs {
     u64* keys_out64;       // LAST: (bucket << 56) | (narrow key << lo_shift); nullptr: the last pass too leaves narrow keys
                            // in keys_out (the caller keeps them as they are: Builder::qkeys32)
     u32* vals_out;
+    int64_t* vals_out64;   // LAST only, may be null: the values also leave as int64 (libsais64 layout: the widening pass of
+                           // libsais64.c:6248-6259 folded into the sort's last store, 8 more bytes written per record
+                           // instead of a separate 4 + 8 byte pass)
     const SegPlan* plan;
     int shift;             // digit of the narrow key
     u32 mask;
@@ -299,6 +302,14 @@ __device__ __forceinline__ void seg_tile(const SegPassArgs& a, const u32 flat, c
     for (int j = 0; j < ITEMS; ++j)
         if (FULL || (woff + j * WAVE) < tile_n) s_vals[pos[j]] = val[j];
     __syncthreads();
+    if (LAST && a.vals_out64) {   // uniform
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const u32 p = k * BLOCK + tid;
+            if (FULL || p < tile_n) { const u32 v = s_vals[p]; a.vals_out[gidx[k]] = v; a.vals_out64[gidx[k]] = (int64_t)v; }
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
         const u32 p = k * BLOCK + tid;
@@ -736,7 +747,7 @@ inline int narrow_text_histogram(RadixWorkspace& ws, NarrowWorkspace& nw, hipStr
 // record less written here, 4 less read by whoever consumes the keys).
 inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_t stream, u64* keysA, u32* valsA, u64* keysB,
                              u32* valsB, u32 n, int begin_bit, u64** keys_res, u32** vals_res, const TextSource* src = nullptr,
-                             bool keep_narrow = false) {
+                             bool keep_narrow = false, int64_t* vals_res64 = nullptr) {
     int rc;
     const int lo_bits = 56 - begin_bit;                       // 1 .. 32
     const int np = (lo_bits + RADIX_BITS - 1) / RADIX_BITS;   // narrow passes, 1 .. 4
@@ -797,6 +808,7 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
         SegPassArgs a;
         a.keys_in = kin; a.vals_in = vin; a.keys_out = kout; a.keys_out64 = keep_narrow ? nullptr : reinterpret_cast<u64*>(kout);
         a.vals_out = vout;
+        a.vals_out64 = last ? vals_res64 : nullptr;
         a.plan = nw.plan;
         a.shift = RADIX_BITS * p;
         a.mask = (1u << bits_p) - 1u;
@@ -810,7 +822,7 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
         if ((rc = ws.timer.start(stream, last ? 3 : 2))) return rc;
         if (last) hipLaunchKernelGGL((seg_onesweep_kernel<512, SEG_ITEMS, true>), dim3(flat_max), dim3(512), 0, stream, a);
         else hipLaunchKernelGGL((seg_onesweep_kernel<512, SEG_ITEMS, false>), dim3(flat_max), dim3(512), 0, stream, a);
-        const u64 pass_bytes = (u64)n * ((last && !keep_narrow) ? 20u : 16u);
+        const u64 pass_bytes = (u64)n * ((last && !keep_narrow) ? 20u : 16u) + ((last && vals_res64) ? (u64)n * 8u : 0u);
         if ((rc = ws.timer.stop(stream, pass_bytes))) return rc;
         ws.pass_records += n; ws.pass_bytes += pass_bytes; ws.passes += 1;
         u32* tk = kin; kin = kout; kout = tk;

@@ -762,6 +762,16 @@ __global__ __launch_bounds__(256) void widen_kernel(const u32* __restrict__ sa, 
     for (u64 i = done + t0; i < n; i += stride) out[i] = (int64_t)sa[i];
 }
 
+// sa64[slot] = sa[slot] for the slots of a list (the suffixes that were still tied after the initial sort: whatever
+// refined them wrote the u32 array only; the int64 copy that the sort's last pass left is brought up to date here)
+__global__ void widen_patch_kernel(const u32* __restrict__ slots, u32 m, const u32* __restrict__ sa, int64_t* __restrict__ out) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+        const u32 s = slots[i];
+        out[s] = (int64_t)sa[s];
+    }
+}
+
 // entries of an adopted suffix array that cannot be suffix positions (>= n): sa_hip_index_load refuses the array
 __global__ void sa_range_check_kernel(const u32* __restrict__ sa, u64 n, u64* __restrict__ bad) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
@@ -920,7 +930,7 @@ struct Builder {
     // persistent buffers
     DevBuf text, keys0, keys1, vals0, vals1, flags, counts, small, isa;
     // round pool
-    DevBuf apos0, apos1, aidx, gid, rkeys0, rkeys1, ridx0, ridx1, lf, tile_last, carry;
+    DevBuf apos0, apos1, apos2, aidx, gid, rkeys0, rkeys1, ridx0, ridx1, lf, tile_last, carry;
     RadixWorkspace radix;
     NarrowWorkspace narrow;
     u32* sa = nullptr;        // points into vals0/vals1 after a build (or into sa_own after load)
@@ -947,6 +957,17 @@ struct Builder {
     bool fin_useful = true;           // per build: cleared when a run resolves less than a quarter of what it looked at
     bool use_pilot = true;            // SA_HIP_PILOT: 0 = initial key length from the byte distribution alone
     DevBuf fin_flag;                  // u8[M]: per list position, final / head marks of the finisher
+    // the slot lists of the active set: the next compaction writes into lst_nxt.  With an int64 copy to keep up to date the
+    // FIRST list (apos0) is left alone -- it names every slot that is written after the sort -- and later lists
+    // ping-pong between apos1 and apos2.
+    u32* lst_cur = nullptr;
+    u32* lst_nxt = nullptr;
+    bool lst_first = true, lst_keep_first = false;
+    void swap_lists() {
+        if (lst_keep_first && lst_first) { lst_cur = lst_nxt; lst_nxt = apos2.as<u32>(); }
+        else { u32* t = lst_cur; lst_cur = lst_nxt; lst_nxt = t; }
+        lst_first = false;
+    }
     u32 fin_count_max = FIN_COUNT_MAX;   // SA_HIP_FIN_COUNT_MAX
     int fin_radix_chars = FIN_RADIX_CHARS;   // SA_HIP_FIN_RADIX_CHARS
     u64 local_records = 0, big_records = 0;   // of the last build: records sorted in LDS / through the big-group list
@@ -1041,7 +1062,7 @@ struct Builder {
         return 0;
     }
     void destroy() {
-        DevBuf* all[] = {&text, &keys0, &keys1, &vals0, &vals1, &flags, &counts, &small, &isa, &apos0, &apos1, &aidx,
+        DevBuf* all[] = {&text, &keys0, &keys1, &vals0, &vals1, &flags, &counts, &small, &isa, &apos0, &apos1, &apos2, &aidx,
                          &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir, &dbg, &done, &pilot,
                          &gstart, &loc_tiles, &big_keys, &big_vals, &fin_flag};
         for (DevBuf* b : all) b->release();
@@ -1356,7 +1377,9 @@ struct Builder {
 
     // Groups that fit a tile are refined to the end in LDS (group_finish.hpp); what it resolves leaves the active list.
     // In: the active list (apos_cur, aidx, gid) of M records in G groups at depth h.  Out: M, G, the lists compacted.
-    int run_group_finisher(const CodeMap& map, int b, u32 L, u64 h, u32& M, u32& G, u32*& apos_cur, u32*& apos_nxt, u32* tot) {
+    int run_group_finisher(const CodeMap& map, int b, u32 L, u64 h, u32& M, u32& G, u32* tot) {
+        u32*& apos_cur = lst_cur;
+        u32*& apos_nxt = lst_nxt;
         int rc;
         u32 ntiles = div_up(M, FIN_TILE);
         if ((rc = gstart.ensure(((size_t)G + 2) * 4))) return rc;
@@ -1401,7 +1424,7 @@ struct Builder {
             if (tot[0]) {
                 SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
                 launch_compact(lf.as<u8>(), M, tot[0], apos_cur, ridx0.as<u32>(), apos_nxt, aidx.as<u32>(), gid.as<u32>());
-                u32* t = apos_cur; apos_cur = apos_nxt; apos_nxt = t;
+                swap_lists();
             }
             M = tot[0];
             G = tot[1];
@@ -1410,7 +1433,10 @@ struct Builder {
     }
 
     // The device build.  Text already resident in text.p[0..n_).
-    int build(u64 n_, u32 L) {
+    // sa64_out (may be null): the suffix array also in libsais64 layout, int64[n] in a device buffer of the caller.
+    // On the narrow-record plan the sort's last pass writes it next to the u32 array and the slots refined afterwards
+    // are patched from the first active list; otherwise one widening pass at the end.
+    int build(u64 n_, u32 L, int64_t* sa64_out = nullptr) {
         int rc;
         memset(&stats, 0, sizeof stats);
         local_records = big_records = 0;
@@ -1431,10 +1457,12 @@ struct Builder {
         qkeys = nullptr;
         qkeys32 = nullptr;
         dir_ready = false;
+        stats.widen_fused = 0;
         if (n == 0) return finish_stats();
         if (n == 1) {
             SA_HIP_CHECK(hipMemsetAsync(sa, 0, 4, stream));
             SA_HIP_CHECK(hipMemsetAsync(flags.p, 1, 1, stream));
+            if (sa64_out) SA_HIP_CHECK(hipMemsetAsync(sa64_out, 0, 8, stream));
             return finish_stats();
         }
         const int k0 = choose_initial_chars(b, L);
@@ -1467,7 +1495,8 @@ struct Builder {
             TextSource src;
             src.text = text.as<u8>(); src.b = b; src.k0 = k0;
             if ((rc = radix_sort_narrow(radix, narrow, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(),
-                                        n32, begin_bit, &kres, &vres, text_pass ? &src : nullptr, keep_narrow))) return rc;
+                                        n32, begin_bit, &kres, &vres, text_pass ? &src : nullptr, keep_narrow, sa64_out))) return rc;
+            if (sa64_out) stats.widen_fused = 1;
         } else if ((rc = radix_sort_pairs(radix, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(), n32,
                                           begin_bit, 64, true, fuse_hist, &kres, &vres))) return rc;
         sa = vres;
@@ -1504,8 +1533,16 @@ struct Builder {
             // first compaction: domain = whole SA
             launch_compact(flags.as<u8>(), n32, M, nullptr, sa, apos0.as<u32>(), aidx.as<u32>(), gid.as<u32>());
         }
-        u32* apos_cur = apos0.as<u32>();
-        u32* apos_nxt = apos1.as<u32>();
+        const u32 M0 = (M && (L == 0 || h < L)) ? M : 0;   // the first active list (apos0) stays: the slots an int64 copy has to be patched at
+        lst_cur = apos0.as<u32>();
+        lst_nxt = apos1.as<u32>();
+        lst_first = true;
+        lst_keep_first = M0 && stats.widen_fused;
+        if (lst_keep_first) {
+            if ((rc = apos2.ensure((size_t)M0 * 4))) return rc;
+        }
+        u32*& apos_cur = lst_cur;
+        u32*& apos_nxt = lst_nxt;
         const int rb = bits_for(n + 1);
 
         // tiny-group finisher: pairs .. octets of tied suffixes are ordered by direct comparison
@@ -1526,7 +1563,7 @@ struct Builder {
                 if (tot[0]) {
                     SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
                     launch_compact(lf.as<u8>(), M, tot[0], apos_cur, ridx0.as<u32>(), apos_nxt, aidx.as<u32>(), gid.as<u32>());
-                    u32* t = apos_cur; apos_cur = apos_nxt; apos_nxt = t;
+                    swap_lists();
                 }
                 M = tot[0];
                 G = tot[1];
@@ -1538,7 +1575,7 @@ struct Builder {
             // groups that fit a tile are finished in LDS, whatever their number of rounds; the global round below is for
             // the rest (an average group of more than half a tile: hardly anything fits)
             if (group_finish && fin_useful && !have_isa && (u64)M <= (u64)G * (FIN_CAP / 2)) {
-                if ((rc = run_group_finisher(map, b, L, h, M, G, apos_cur, apos_nxt, tot))) return rc;
+                if ((rc = run_group_finisher(map, b, L, h, M, G, tot))) return rc;
                 if (!M) break;
             }
             const int gb = bits_for(G);
@@ -1613,13 +1650,20 @@ struct Builder {
             const u32 M_next = tot[0];
             if (M_next && (L == 0 || h < L)) {
                 launch_compact(lf.as<u8>(), M, M_next, apos_cur, vres, apos_nxt, aidx.as<u32>(), gid.as<u32>());
-                u32* t = apos_cur; apos_cur = apos_nxt; apos_nxt = t;
+                swap_lists();
             }
             M = M_next;
             G = tot[1];
             if (stats.rounds > (debug_rounds ? 40u : 200u)) return fail(SA_HIP_EINTERNAL, "refinement did not converge");
         }
         stats.final_depth = (u32)(h > 0xFFFFFFFFull ? 0xFFFFFFFFull : h);
+        if (sa64_out) {
+            if (!stats.widen_fused)
+                hipLaunchKernelGGL(widen_kernel, dim3(stream_grid(n / 4 + 1, 256)), dim3(256), 0, stream, (const u32*)sa, n, sa64_out);
+            else if (M0)
+                hipLaunchKernelGGL(widen_patch_kernel, dim3(stream_grid(M0, 256)), dim3(256), 0, stream, (const u32*)apos0.as<u32>(), M0,
+                                   (const u32*)sa, sa64_out);
+        }
         if ((rc = build_directory())) return rc;
         return finish_stats();
     }

@@ -172,6 +172,21 @@ int sa_hip_index_build_device(sa_hip_index* idx, const void* T_dev, uint64_t n, 
     return rc;
 }
 
+int sa_hip_index_build_device64(sa_hip_index* idx, const void* T_dev, uint64_t n, uint32_t max_suffix_length, void* sa64_dev) {
+    if (!idx || (!T_dev && n) || (!sa64_dev && n)) return fail(SA_HIP_EINVAL, "sa_hip_index_build_device64: NULL argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    if (n > idx->b.n_max) return fail(SA_HIP_EINVAL, "sa_hip_index_build_device64: n exceeds the index capacity");
+    if (n && T_dev != idx->b.text.p)
+        SA_HIP_CHECK(hipMemcpyAsync(idx->b.text.p, T_dev, n, hipMemcpyDeviceToDevice, idx->stream));
+    idx->has_index = false;
+    idx->widen_ms = 0.0;
+    rc = idx->b.build(n, max_suffix_length, static_cast<int64_t*>(sa64_dev));
+    idx->has_index = (rc == 0);
+    return rc;
+}
+
 static int load_common(sa_hip_index* idx, const void* T, const void* SA, uint64_t n, uint32_t L, hipMemcpyKind kind) {
     std::lock_guard<std::mutex> g(idx->mu);
     int rc = set_device(idx->device);

@@ -258,7 +258,10 @@ def test_group_finisher_matches_global_rounds(gpu, oracle, monkeypatch):
             ("d1_pairs_L10", synth.d1_uniform27(4_500_000), 10, {"SA_HIP_TINY": "0"}),
             ("d2_300k", st["d2_300k"], 0, {}), ("repeat_block", st["repeat_block"], 0, {}), ("fib", st["fib"], 0, {}),
             ("all_a_70000", st["all_a_70000"], 0, {}), ("period7", st["period7"], 0, {}), ("r2_30000", st["r2_30000"], 0, {}),
-            ("with_nul", st["with_nul"], 0, {}), ("highbit", st["highbit"], 0, {})]
+            ("with_nul", st["with_nul"], 0, {}), ("highbit", st["highbit"], 0, {}),
+            # every byte value occurs: 9-bit codes (code 256 does not fit a byte)
+            ("bytes256", np.concatenate([np.arange(256, dtype=np.uint8), rng.integers(0, 256, 3000, dtype=np.uint8)] * 3), 0, {}),
+            ("perm256", st["perm256"], 0, {}), ("r256_30000", st["r256_30000"], 0, {})]
     for name, t, L, env in runs:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -284,3 +287,35 @@ def test_group_finisher_matches_global_rounds(gpu, oracle, monkeypatch):
             assert np.array_equal(got["1"], oracle.sais(t).astype(np.uint32)), name
         elif L:
             assert np.array_equal(got["1"], oracle.truncated_sa(t, L)), name
+
+
+def test_build_device64_is_the_libsais64_layout(gpu, oracle, monkeypatch):
+    """sa_hip_index_build_device64 (bench.py's 64-bit build): the int64 array equals (int64)SA whether it comes out of
+    the narrow sort's last pass + the patch of the refined slots (near-random text with tied pairs, word text with
+    millions of refined slots through finisher and rounds, a truncated build) or from the widening pass at the end
+    (texts too short for the narrow plan, 12-byte-record plan)."""
+    import torch
+    from suffixarray_amd import synth
+    runs = [("d1", synth.d1_uniform27(4_500_000), 0, {}, True), ("d1_L12", synth.d1_uniform27(4_500_000), 12, {}, True),
+            ("words", synth.d2_words(5_000_000), 0, {"SA_HIP_PILOT": "0"}, True), ("words_L20", synth.d2_words(5_000_000), 20, {"SA_HIP_PILOT": "0"}, True),
+            ("words_plain", synth.d2_words(5_000_000), 0, {"SA_HIP_NARROW": "0"}, False), ("small", cases.small_texts()["d2_300k"], 0, {}, False),
+            ("banana", cases.small_texts()["banana"], 0, {}, False), ("len1", cases.small_texts()["len1"], 0, {}, False)]
+    for name, t, L, env, fused in runs:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with gpu.DeviceIndex(t.size, 0) as idx:
+            idx.build(t, L)   # uploads the text
+            out = torch.full((t.size + 2,), -7, dtype=torch.int64, device="cuda:0")
+            torch.cuda.synchronize()
+            idx.build_device64(idx.text_dev, t.size, out.data_ptr(), L)
+            idx.sync()
+            st = idx.build_stats()
+            assert bool(st["widen_fused"]) == fused, (name, st)
+            assert idx.verify() == 0, name
+            got = out.cpu().numpy()
+            assert np.array_equal(got[:t.size], idx.sa_u32().astype(np.int64)), name
+            assert (got[t.size:] == -7).all()
+            exp = oracle.truncated_sa(t, L) if L else oracle.sais(t)
+            assert np.array_equal(got[:t.size], exp.astype(np.int64)), name
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
