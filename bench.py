@@ -148,7 +148,70 @@ def secondary_builds(_capi, synth, device):
             out[name] = {"n_chars": n, "build_ms": min(ms), "chars_per_s": n / (min(ms) / 1e3), "verify_violations": idx.verify(),
                          "initial_chars": st["initial_chars"], "rounds": st["rounds"], "active_total": st["active_total"]}
         del text
+    out["config5_csv_50M_rows"] = config5_csv(_capi)
     return out
+
+
+def config5_csv(_capi, rows=50_000_000, budget_s=12.0):
+    """BASELINE config 5 with the reference's own measurement protocol (tests/test.py:99-141): build from the CSV column,
+    sample names from the column (upper-cased, test.py:103-106), time each query_records with perf_counter (122-127),
+    report build seconds, mean and median microseconds and the mean number of results (131-136).  10 000 samples as
+    in the reference, cut short when `budget_s` of query time is used up (the count is reported)."""
+    import tempfile
+    from suffixarray_amd import SuffixArray
+    tmp = tempfile.mkdtemp(prefix="sa_hip_c5_")
+    path = os.path.join(tmp, "companies.csv")
+    try:
+        _capi.synth_csv(path, rows, 1)
+        t0 = time.perf_counter()
+        s = SuffixArray(csv_file=path, search_column="company_name", max_suffix_length=32)
+        t_index = time.perf_counter() - t0
+        idx = s._index
+        st = idx.build_stats()
+        n = idx.n
+        idx.build_device(idx.text_dev, n, 32)   # second build: allocations warm
+        st2 = idx.build_stats()
+        violations = idx.verify()
+        rng = np.random.default_rng(0)
+        # sample names straight from the file's rows (the column of `id,company_name,country`)
+        size = os.path.getsize(path)
+        sample = []
+        with open(path, "rb") as f:
+            for o in np.sort(rng.integers(0, size - 4096, 10_000)):
+                f.seek(int(o))
+                lines = f.read(4096).split(b"\n")
+                if len(lines) >= 3:
+                    sample.append(next(_csv_reader([lines[1].decode()]))[1].upper())
+        lat, nres = [], []
+        t_all = time.perf_counter()
+        for q in sample:
+            t0 = time.perf_counter()
+            r = s.query_records(q)
+            lat.append((time.perf_counter() - t0) * 1e6)
+            nres.append(len(r))
+            if time.perf_counter() - t_all > budget_s:
+                break
+        lat = np.array(lat)
+        out = {"rows": rows, "file_bytes": size, "n_chars": n, "max_suffix_length": 32,
+               "index_seconds_end_to_end": t_index, "device_build_ms_first": st["total_ms"], "device_build_ms": st2["total_ms"],
+               "chars_per_s": n / (st2["total_ms"] / 1e3), "verify_violations": violations, "rounds": st2["rounds"],
+               "finisher_resolved": st2["finisher_resolved"],
+               "query_records": {"samples": int(lat.size), "mean_us": float(lat.mean()), "median_us": float(np.median(lat)),
+                                 "mean_results": float(np.mean(nres)), "k": 1000,
+                                 "protocol": "tests/test.py:99-141 (sampled names, upper-cased, perf_counter per query)"}}
+        s.close()
+        return out
+    finally:
+        try:
+            os.remove(path)
+            os.rmdir(tmp)
+        except OSError:
+            pass
+
+
+def _csv_reader(lines):
+    import csv
+    return csv.reader(lines)
 
 
 def main():

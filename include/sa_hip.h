@@ -58,8 +58,10 @@ int32_t sa_hip_libsais(const uint8_t* T, int32_t* SA, int32_t n, int32_t fs, int
 /* replaces libsais_omp (libsais.h:121, libsais.c:6791).  threads is validated (>= 0) and
  * otherwise ignored: the device pipeline has no host thread pool. */
 int32_t sa_hip_libsais_omp(const uint8_t* T, int32_t* SA, int32_t n, int32_t fs, int32_t* freq, int32_t threads);
-/* replaces libsais64 (libsais64.h:61, libsais64.c:6657).  n <= UINT32_MAX - 1: 32-bit device
- * build + widening kernel (the reference does the same on the CPU, libsais64.c:6670-6682). */
+/* replaces libsais64 (libsais64.h:61, libsais64.c:6657) for n <= UINT32_MAX - 1: 32-bit device
+ * build + widening (the reference does the same on the CPU for n <= INT32_MAX, libsais64.c:6670-6682).
+ * n > 2^32 - 2 is REFUSED (-1): the true 64-bit path of the reference (libsais64.c:6684 -> libsais64_main) has no
+ * counterpart here -- one index holds at most 2^32 - 2 bytes of text (outside every BASELINE configuration). */
 int64_t sa_hip_libsais64(const uint8_t* T, int64_t* SA, int64_t n, int64_t fs, int64_t* freq);
 /* replaces libsais64_omp (libsais64.h:86, libsais64.c:6783). */
 int64_t sa_hip_libsais64_omp(const uint8_t* T, int64_t* SA, int64_t n, int64_t fs, int64_t* freq, int64_t threads);
@@ -76,8 +78,9 @@ int sa_hip_construct_truncated_suffix_array(const char* text, sa_hip_SuffixArray
 /* ---- (3) query -------------------------------------------------------------------------- */
 
 /* replaces get_substring_positions (engine.h:229-233, engine.c:869-918): one query, host
- * text (n bytes; a trailing NUL is not required) and host SA.  Uploads text and SA, runs the
- * batched kernel with Q = 1.  For repeated queries use the handle API below. */
+ * text (n bytes; a trailing NUL is not required) and host SA.  COMPATIBILITY SHIM, O(n) PER CALL: it creates a
+ * private index, uploads text and SA and rebuilds the key array and the directory for ONE query.  Anything that
+ * asks more than once must use the handle API below (sa_hip_index_load once, then sa_hip_query_batch). */
 sa_hip_pair_u32 sa_hip_get_substring_positions(const char* str, const sa_hip_SuffixArray_struct* sa,
                                                const char* substring);
 
@@ -162,6 +165,84 @@ int sa_hip_index_sync(sa_hip_index* idx);
  * *violations = 0 means verified.  O(n) device work, 4n bytes of device scratch; the O(n)
  * "sufcheck" that makes bit-exactness testable at n = 1e9 without a CPU oracle run. */
 int sa_hip_index_verify(sa_hip_index* idx, uint64_t* violations);
+
+/* ---- (5) record retrieval: hits -> rows (engine.c:920-999, 1168-1215, 1326-1390; bound at pyx:87-101) -------------- */
+
+/* Row table of the indexed text: row r (a document, or one CSV field) = text[row_text_starts[r], row_text_starts[r+1]);
+ * row_text_starts[0] must be 0 and the offsets ascend.  The table is copied.  Not to be called while queries run on
+ * the same handle. */
+int sa_hip_index_set_rows(sa_hip_index* idx, const uint64_t* row_text_starts, uint64_t num_rows);
+/* ONE query -> the distinct rows that contain the pattern, in SA order of their first hit, at most k of them
+ * (row_ids[0 .. *num_rows)); *range (may be NULL) as in sa_hip_query_batch.  The reference returns one record per HIT
+ * (engine.c:1364-1388); one per ROW is this library's decision. */
+int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t len, uint32_t k, uint64_t* row_ids,
+                            uint32_t* num_rows, sa_hip_pair_u32* range);
+/* The same for a range that a batched query has already found (sa_hip_query_batch: one launch for all the ranges,
+ * then the rows per range). */
+int sa_hip_index_rows_for_range(sa_hip_index* idx, sa_hip_pair_u32 range, uint32_t k, uint64_t* row_ids, uint32_t* num_rows);
+/* Copy the indexed text (n bytes) back to the host (persistence: the CSV-mode text is the extracted column). */
+int sa_hip_index_get_text(sa_hip_index* idx, uint8_t* out_host);
+
+/* CSV-mode index: replaces SuffixArrayIndex + construct_truncated_suffix_array_from_csv_partitioned_mmap_full
+ * (engine.h:163-172, engine.c:1454-1482 -> 461-654): extracts `search_column` of an RFC-4180 file (lower-cased, one
+ * '\n' after every field, header row not indexed, 64-bit file offsets), builds the device index over it with
+ * max_suffix_length and keeps the row tables + a read-only mapping of the file.  One index per file: the 2 GiB
+ * partitioning of the reference (engine.c:1437) is not reproduced (288 GB of HBM; the column must stay below 2^32 - 2
+ * bytes). */
+typedef struct sa_hip_csv_index sa_hip_csv_index;
+int sa_hip_csv_index_create(sa_hip_csv_index** out, const char* csv_file, const char* search_column, uint32_t max_suffix_length,
+                            int device);
+/* Re-open a saved CSV-mode index without parsing or building (persistence; the reference's
+ * read_suffix_array is declared but never defined, engine.h:141): adopts text + SA + row tables; column_names =
+ * num_columns NUL-terminated names back to back. */
+int sa_hip_csv_index_adopt(sa_hip_csv_index** out, const char* csv_file, const uint8_t* text, const uint32_t* SA, uint64_t n,
+                           const uint64_t* row_text_starts, const uint64_t* row_file_offsets, uint64_t num_rows,
+                           const char* column_names, uint32_t num_columns, uint32_t column_index, uint32_t max_suffix_length,
+                           int device);
+void sa_hip_csv_index_destroy(sa_hip_csv_index* c);
+/* The device index underneath (batched queries, statistics, verification); owned by the CSV index. */
+sa_hip_index* sa_hip_csv_index_handle(sa_hip_csv_index* c);
+uint64_t sa_hip_csv_index_num_rows(const sa_hip_csv_index* c);
+uint32_t sa_hip_csv_index_num_columns(const sa_hip_csv_index* c);
+uint32_t sa_hip_csv_index_column_index(const sa_hip_csv_index* c);
+const char* sa_hip_csv_index_column_name(const sa_hip_csv_index* c, uint32_t i);
+/* Borrowed views of the row tables: row_text_starts[num_rows], row_file_offsets[num_rows + 1]. */
+int sa_hip_csv_index_row_tables(const sa_hip_csv_index* c, const uint64_t** row_text_starts, const uint64_t** row_file_offsets);
+
+/* Rows of the file by id, as malloc'ed NUL-terminated strings without the line terminator (records[0 .. n); ownership
+ * as in sa_hip_get_matching_records_file). */
+int sa_hip_csv_index_copy_rows(sa_hip_csv_index* c, const uint64_t* row_ids, uint32_t n, char** records);
+
+/* replaces get_substring_positions_file (engine.h:235-239, engine.c:920-999): the search of CSV mode.  The reference
+ * reads the text per probe from the file (fseek + fread + tolower); here it is the batched kernel with Q = 1 over the
+ * extracted column in HBM.  Result conventions of THAT function: a hit -> inclusive range {first, last} over the
+ * index's suffix array; ANY miss -> {UINT32_MAX, UINT32_MAX} (engine.c:962-965).  `substring` is compared as given
+ * (the reference's caller lower-cases it, pyx:228). */
+sa_hip_pair_u32 sa_hip_get_substring_positions_file(sa_hip_csv_index* c, const char* substring);
+/* replaces get_matching_records_file (engine.h:257-264, engine.c:1326-1390; bound at pyx:94-101, called at pyx:224-232):
+ * appends the rows that contain `substring` to matching_records[*num_matches ...] until *num_matches == k.  Ownership
+ * as in the reference: every row is a malloc'ed NUL-terminated string (engine.c:1382), the caller frees each one
+ * (pyx:262-265; or sa_hip_free_records).  Differences by decision: a row is returned once however
+ * often it contains the pattern, rows come back whole (engine.c:1314 drops the last character), a miss appends
+ * nothing.  Returns 0 or a negative SA_HIP_* code (the reference returns void and exit()s). */
+int sa_hip_get_matching_records_file(sa_hip_csv_index* c, const char* substring, uint32_t k, char** matching_records,
+                                     uint32_t* num_matches);
+/* replaces get_matching_records (engine.h:249-255, engine.c:1168-1215; bound at pyx:87-93): host text + host SA, the
+ * records are the lines of `str` ('\n'-separated documents) that contain the pattern; returns their number (<= k).
+ * Like sa_hip_get_substring_positions this uploads text and SA for ONE query -- O(n) per call: a compatibility shim,
+ * not the fast path (use a handle + sa_hip_index_set_rows + sa_hip_index_query_rows). */
+uint32_t sa_hip_get_matching_records(const char* str, const sa_hip_SuffixArray_struct* sa, const char* substring, uint32_t k,
+                                     char** matching_records);
+/* free() every row of a result table (the table itself belongs to the caller). */
+void sa_hip_free_records(char** records, uint32_t n);
+
+/* replaces init_suffix_array_byte_idxs / free_suffix_array (engine.h:133-140, engine.c:326-349; pyx:68-74): malloc /
+ * free of the caller-side uint32 suffix_array[n] of a SuffixArray_struct for the engine-compatible calls of (2) and
+ * (3).  is_quoted_bitflag is left NULL: the row tables of sa_hip_csv_index replace the reference's per-character
+ * quoted bits (engine.c:637-645), which only serve its newline seeks. */
+int sa_hip_init_suffix_array_byte_idxs(sa_hip_SuffixArray_struct* sa, uint32_t max_suffix_length, uint64_t global_byte_start_idx,
+                                       uint64_t global_byte_end_idx, uint32_t n);
+void sa_hip_free_suffix_array(sa_hip_SuffixArray_struct* sa);
 
 /* ---- instrumentation ---------------------------------------------------------------------- */
 

@@ -6,6 +6,14 @@ in include/sa_hip.h (libsa_hip.so, hand-written HIP for gfx950).  No CPU fallbac
 """
 from . import _capi
 from ._capi import DeviceIndex, SaHipError, PAIR_DTYPE, UINT32_MAX  # noqa: F401
-from .index import SuffixArray  # noqa: F401
+
+
+def __getattr__(name):
+    # the Cython extension is imported on first use (it is built in-tree: `python -m suffixarray_amd.build`)
+    if name == "SuffixArray":
+        from . import index
+        return index.SuffixArray
+    raise AttributeError(name)
+
 
 __all__ = ["SuffixArray", "DeviceIndex", "SaHipError", "PAIR_DTYPE", "UINT32_MAX"]

@@ -25,6 +25,11 @@ EXPORTS = [
     "sa_hip_index_stream", "sa_hip_index_get_sa_u32", "sa_hip_index_get_sa_i64", "sa_hip_index_widen_device",
     "sa_hip_index_get_freq", "sa_hip_query_batch", "sa_hip_query_batch_device",
     "sa_hip_index_get_sa_range", "sa_hip_index_query_hits", "sa_hip_index_sync", "sa_hip_index_verify", "sa_hip_index_build_stats",
+    "sa_hip_index_set_rows", "sa_hip_index_query_rows", "sa_hip_index_rows_for_range", "sa_hip_csv_index_copy_rows", "sa_hip_index_get_text", "sa_hip_csv_index_create", "sa_hip_csv_index_adopt",
+    "sa_hip_csv_index_destroy", "sa_hip_csv_index_handle", "sa_hip_csv_index_num_rows", "sa_hip_csv_index_num_columns",
+    "sa_hip_csv_index_column_index", "sa_hip_csv_index_column_name", "sa_hip_csv_index_row_tables",
+    "sa_hip_get_substring_positions_file", "sa_hip_get_matching_records_file", "sa_hip_get_matching_records", "sa_hip_free_records",
+    "sa_hip_init_suffix_array_byte_idxs", "sa_hip_free_suffix_array",
     "sa_hip_index_query_stats", "sa_hip_csv_extract_column", "sa_hip_csv_free", "sa_hip_synth_csv", "sa_hip_sort_pairs", "sa_hip_synth_uniform27", "sa_hip_last_error", "sa_hip_version",
 ]
 
@@ -153,6 +158,46 @@ def lib():
     L.sa_hip_csv_free.argtypes = [C.POINTER(CsvColumn)]
     L.sa_hip_synth_csv.restype = C.c_int
     L.sa_hip_synth_csv.argtypes = [C.c_char_p, u64, u64]
+    L.sa_hip_index_set_rows.restype = C.c_int
+    L.sa_hip_index_set_rows.argtypes = [vp, vp, u64]
+    L.sa_hip_index_query_rows.restype = C.c_int
+    L.sa_hip_index_query_rows.argtypes = [vp, C.c_char_p, u64, u32, vp, C.POINTER(u32), C.POINTER(PairU32)]
+    L.sa_hip_index_rows_for_range.restype = C.c_int
+    L.sa_hip_index_rows_for_range.argtypes = [vp, PairU32, u32, vp, C.POINTER(u32)]
+    L.sa_hip_index_get_text.restype = C.c_int
+    L.sa_hip_index_get_text.argtypes = [vp, vp]
+    L.sa_hip_csv_index_create.restype = C.c_int
+    L.sa_hip_csv_index_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, u32, C.c_int]
+    L.sa_hip_csv_index_adopt.restype = C.c_int
+    L.sa_hip_csv_index_adopt.argtypes = [C.POINTER(vp), C.c_char_p, vp, vp, u64, vp, vp, u64, C.c_char_p, u32, u32, u32, C.c_int]
+    L.sa_hip_csv_index_destroy.restype = None
+    L.sa_hip_csv_index_destroy.argtypes = [vp]
+    L.sa_hip_csv_index_handle.restype = vp
+    L.sa_hip_csv_index_handle.argtypes = [vp]
+    L.sa_hip_csv_index_num_rows.restype = u64
+    L.sa_hip_csv_index_num_rows.argtypes = [vp]
+    L.sa_hip_csv_index_num_columns.restype = u32
+    L.sa_hip_csv_index_num_columns.argtypes = [vp]
+    L.sa_hip_csv_index_column_index.restype = u32
+    L.sa_hip_csv_index_column_index.argtypes = [vp]
+    L.sa_hip_csv_index_column_name.restype = C.c_char_p
+    L.sa_hip_csv_index_column_name.argtypes = [vp, u32]
+    L.sa_hip_csv_index_row_tables.restype = C.c_int
+    L.sa_hip_csv_index_row_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.sa_hip_csv_index_copy_rows.restype = C.c_int
+    L.sa_hip_csv_index_copy_rows.argtypes = [vp, vp, u32, C.POINTER(vp)]
+    L.sa_hip_get_substring_positions_file.restype = PairU32
+    L.sa_hip_get_substring_positions_file.argtypes = [vp, C.c_char_p]
+    L.sa_hip_get_matching_records_file.restype = C.c_int
+    L.sa_hip_get_matching_records_file.argtypes = [vp, C.c_char_p, u32, C.POINTER(vp), C.POINTER(u32)]
+    L.sa_hip_get_matching_records.restype = u32
+    L.sa_hip_get_matching_records.argtypes = [vp, C.POINTER(SuffixArrayStruct), C.c_char_p, u32, C.POINTER(vp)]
+    L.sa_hip_free_records.restype = None
+    L.sa_hip_free_records.argtypes = [C.POINTER(vp), u32]
+    L.sa_hip_init_suffix_array_byte_idxs.restype = C.c_int
+    L.sa_hip_init_suffix_array_byte_idxs.argtypes = [C.POINTER(SuffixArrayStruct), u32, u64, u64, u32]
+    L.sa_hip_free_suffix_array.restype = None
+    L.sa_hip_free_suffix_array.argtypes = [C.POINTER(SuffixArrayStruct)]
     L.sa_hip_sort_pairs.restype = C.c_int
     L.sa_hip_sort_pairs.argtypes = [vp, vp, u64, C.c_int, C.c_int, C.c_int]
     L.sa_hip_synth_uniform27.restype = None
@@ -193,7 +238,20 @@ class DeviceIndex:
         self._lib = lib()
         check(self._lib.sa_hip_index_create(C.byref(self._h), int(n_max), int(device)))
 
+    @classmethod
+    def from_handle(cls, handle, owner=None):
+        """Non-owning wrapper of an existing sa_hip_index* (an integer); `owner` is kept alive with it."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(int(handle))
+        self._lib = lib()
+        self._borrowed = True
+        self._owner = owner
+        return self
+
     def close(self):
+        if getattr(self, "_borrowed", False):
+            self._h = C.c_void_p()
+            return
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.sa_hip_index_destroy(self._h)
             self._h = C.c_void_p()
@@ -364,6 +422,75 @@ def get_substring_positions(text, sa, max_suffix_length, substring):
     st.n = t.size
     r = lib().sa_hip_get_substring_positions(t.ctypes.data, C.byref(st), bytes(substring))
     return (r.first, r.second)
+
+
+class CsvIndex:
+    """sa_hip_csv_index through ctypes: the C seam of CSV mode exactly as a C caller sees it (the tests of the record
+    retrieval entry points go through this; the Python class binds the same functions from Cython)."""
+
+    def __init__(self, csv_file, search_column, max_suffix_length=32, device=0):
+        self._lib = lib()
+        self._h = C.c_void_p()
+        check(self._lib.sa_hip_csv_index_create(C.byref(self._h), os.fsencode(csv_file), search_column.encode("utf-8"),
+                                                int(max_suffix_length), int(device)))
+
+    def close(self):
+        if self._h:
+            self._lib.sa_hip_csv_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def index(self):
+        return DeviceIndex.from_handle(self._lib.sa_hip_csv_index_handle(self._h), self)
+
+    @property
+    def num_rows(self):
+        return int(self._lib.sa_hip_csv_index_num_rows(self._h))
+
+    @property
+    def columns(self):
+        return [self._lib.sa_hip_csv_index_column_name(self._h, i).decode("utf-8") for i in range(self._lib.sa_hip_csv_index_num_columns(self._h))]
+
+    def get_substring_positions_file(self, substring: bytes):
+        r = self._lib.sa_hip_get_substring_positions_file(self._h, substring)
+        return (r.first, r.second)
+
+    def get_matching_records_file(self, substring: bytes, k, already=()):
+        """-> list of row bytes; `already`: rows that occupy the front of the table (num_matches starts at their count)."""
+        table = (C.c_void_p * max(k, 1))()
+        num = C.c_uint32(len(already))
+        check(self._lib.sa_hip_get_matching_records_file(self._h, substring, k, table, C.byref(num)))
+        out = [C.string_at(table[i]) for i in range(len(already), num.value)]
+        tail = (C.c_void_p * max(num.value - len(already), 1))(*[table[i] for i in range(len(already), num.value)])
+        self._lib.sa_hip_free_records(tail, num.value - len(already))
+        return out, num.value
+
+
+def get_matching_records(text, sa, max_suffix_length, substring: bytes, k):
+    """sa_hip_get_matching_records: host text + host SA, engine.c:1168-1215's calling convention."""
+    t = as_u8(text)
+    s = np.ascontiguousarray(sa, dtype=np.uint32)
+    st = SuffixArrayStruct()
+    st.suffix_array = s.ctypes.data
+    st.max_suffix_length = max_suffix_length
+    st.n = t.size
+    table = (C.c_void_p * max(k, 1))()
+    n = lib().sa_hip_get_matching_records(t.ctypes.data, C.byref(st), substring, k, table)
+    out = [C.string_at(table[i]) for i in range(n)]
+    lib().sa_hip_free_records(table, n)
+    return out
 
 
 class _CsvOwner:

@@ -11,6 +11,7 @@
 #include "sa_build.hpp"
 #include "sa_query.hpp"
 #include "csv_ingest.hpp"
+#include "records.hpp"
 
 using namespace sa;
 
@@ -29,6 +30,19 @@ struct sa_hip_index {
     hipEvent_t w_begin = nullptr, w_end = nullptr;   // sa_hip_index_widen_device
     double widen_ms = 0.0;                           // < 0: recorded, not yet resolved
     sa_hip_query_stats qstats{};
+    std::vector<u64> row_starts;   // sa_hip_index_set_rows: offset of every row (document, CSV field) in the indexed text
+};
+
+// CSV-mode index (SuffixArrayIndex of the reference, engine.h:163-172): the device index over one column + the row
+// tables + the memory-mapped file the rows are copied out of
+struct sa_hip_csv_index {
+    sa_hip_index* idx = nullptr;
+    std::vector<u64> row_file_offsets;   // num_rows + 1
+    std::vector<std::string> columns;
+    u32 column_index = 0;
+    std::string path;
+    const u8* map = nullptr;
+    u64 map_len = 0;
 };
 
 namespace {
@@ -423,6 +437,260 @@ int sa_hip_index_query_stats(const sa_hip_index* idx_c, sa_hip_query_stats* out)
     }
     *out = idx->qstats;
     return 0;
+}
+
+// ---- record retrieval (engine.c:920-999, 1168-1215, 1326-1390; pyx:87-101) -----------------------
+
+int sa_hip_index_set_rows(sa_hip_index* idx, const uint64_t* row_text_starts, uint64_t num_rows) {
+    if (!idx || (!row_text_starts && num_rows)) return fail(SA_HIP_EINVAL, "sa_hip_index_set_rows: NULL argument");
+    if (num_rows && row_text_starts[0] != 0) return fail(SA_HIP_EINVAL, "sa_hip_index_set_rows: the first row must start at offset 0");
+    for (uint64_t r = 1; r < num_rows; ++r)
+        if (row_text_starts[r] < row_text_starts[r - 1]) return fail(SA_HIP_EINVAL, "sa_hip_index_set_rows: offsets must ascend");
+    std::lock_guard<std::mutex> g(idx->mu);
+    try { idx->row_starts.assign(row_text_starts, row_text_starts + num_rows); }
+    catch (const std::bad_alloc&) { return fail(SA_HIP_ENOMEM, "sa_hip_index_set_rows: out of host memory"); }
+    return 0;
+}
+
+int sa_hip_index_get_text(sa_hip_index* idx, uint8_t* out_host) {
+    if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_get_text: NULL index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_text: no index");
+    if (!out_host && idx->b.n) return fail(SA_HIP_EINVAL, "sa_hip_index_get_text: NULL output");
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    if (idx->b.n) SA_HIP_CHECK(hipMemcpyAsync(out_host, idx->b.text.p, (size_t)idx->b.n, hipMemcpyDeviceToHost, idx->stream));
+    SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+    return 0;
+}
+
+int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t len, uint32_t k, uint64_t* row_ids,
+                            uint32_t* num_rows, sa_hip_pair_u32* range) {
+    if (!idx || !num_rows || (!row_ids && k) || (!pattern && len)) return fail(SA_HIP_EINVAL, "sa_hip_index_query_rows: NULL argument");
+    *num_rows = 0;
+    sa_hip_pair_u32 rg;
+    u32 nh = 0;
+    const u32 cap = k ? std::min<u32>(std::max<u32>(4u * k, 1024u), QH_MAX_HITS) : 0u;
+    try {
+        std::vector<u32> first(cap ? cap : 1);
+        int rc = sa_hip_index_query_hits(idx, pattern, len, cap, &rg, first.data(), &nh);
+        if (rc) return rc;
+        if (range) *range = rg;
+        const std::vector<u64>& starts = idx->row_starts;   // (set_rows must not run concurrently with queries on the handle)
+        if (starts.empty() && k) return fail(SA_HIP_EINVAL, "sa_hip_index_query_rows: no row table (sa_hip_index_set_rows)");
+        std::vector<u64> rows;
+        rc = distinct_rows(starts, rg, k, first.data(), nh,
+                           [&](u64 pos, u64 count, u32* out) { return sa_hip_index_get_sa_range(idx, pos, count, out); }, rows);
+        if (rc) return rc;
+        for (size_t i = 0; i < rows.size(); ++i) row_ids[i] = rows[i];
+        *num_rows = (uint32_t)rows.size();
+    } catch (const std::bad_alloc&) { return fail(SA_HIP_ENOMEM, "sa_hip_index_query_rows: out of host memory"); }
+    return 0;
+}
+
+int sa_hip_index_rows_for_range(sa_hip_index* idx, sa_hip_pair_u32 range, uint32_t k, uint64_t* row_ids, uint32_t* num_rows) {
+    if (!idx || !num_rows || (!row_ids && k)) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: NULL argument");
+    *num_rows = 0;
+    if (range.first != 0xFFFFFFFFu && (u32)(range.second - range.first + 1u) != 0u &&
+        ((u64)range.second >= idx->b.n || range.first > range.second)) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: range outside the suffix array");
+    try {
+        const std::vector<u64>& starts = idx->row_starts;
+        if (starts.empty() && k) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: no row table (sa_hip_index_set_rows)");
+        std::vector<u64> rows;
+        int rc = distinct_rows(starts, range, k, nullptr, 0,
+                               [&](u64 pos, u64 count, u32* out) { return sa_hip_index_get_sa_range(idx, pos, count, out); }, rows);
+        if (rc) return rc;
+        for (size_t i = 0; i < rows.size(); ++i) row_ids[i] = rows[i];
+        *num_rows = (uint32_t)rows.size();
+    } catch (const std::bad_alloc&) { return fail(SA_HIP_ENOMEM, "sa_hip_index_rows_for_range: out of host memory"); }
+    return 0;
+}
+
+static int csv_index_finish(sa_hip_csv_index* c) {
+    const int fd = open(c->path.c_str(), O_RDONLY);
+    if (fd < 0) return fail(SA_HIP_EINVAL, "sa_hip_csv_index: cannot open file", c->path.c_str());
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); return fail(SA_HIP_EINVAL, "sa_hip_csv_index: fstat failed", c->path.c_str()); }
+    c->map_len = (u64)sb.st_size;
+    if (!c->row_file_offsets.empty() && c->row_file_offsets.back() > c->map_len) { close(fd); return fail(SA_HIP_EINVAL, "sa_hip_csv_index: row table exceeds the file"); }
+    void* m = c->map_len ? mmap(nullptr, c->map_len, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    close(fd);
+    if (c->map_len && m == MAP_FAILED) return fail(SA_HIP_ENOMEM, "sa_hip_csv_index: mmap failed", c->path.c_str());
+    c->map = static_cast<const u8*>(m);
+    return 0;
+}
+
+void sa_hip_csv_index_destroy(sa_hip_csv_index* c) {
+    if (!c) return;
+    if (c->map) munmap(const_cast<u8*>(c->map), c->map_len);
+    if (c->idx) sa_hip_index_destroy(c->idx);
+    delete c;
+}
+
+int sa_hip_csv_index_create(sa_hip_csv_index** out, const char* csv_file, const char* search_column, uint32_t max_suffix_length,
+                            int device) {
+    if (!out || !csv_file || !search_column) return fail(SA_HIP_EINVAL, "sa_hip_csv_index_create: NULL argument");
+    *out = nullptr;
+    if (max_suffix_length == 0) return fail(SA_HIP_EINVAL, "sa_hip_csv_index_create: max_suffix_length must be >= 1");
+    sa_hip_csv_column col;
+    // the HIP runtime of this process (context, code object: ~0.2 s the first time) comes up while the host parses
+    std::thread warm;
+    try { warm = std::thread([device]() { if (hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr); }); } catch (...) {}
+    int rc = sa_hip_csv_extract_column(csv_file, search_column, &col);
+    if (warm.joinable()) warm.join();
+    if (rc) return rc;
+    sa_hip_csv_index* c = nullptr;
+    try {
+        c = new sa_hip_csv_index();
+        c->path = csv_file;
+        c->column_index = col.column_index;
+        const char* p = col.column_names;
+        for (u32 i = 0; i < col.num_columns; ++i) { c->columns.emplace_back(p); p += c->columns.back().size() + 1; }
+        c->row_file_offsets.assign(col.row_file_offsets, col.row_file_offsets + col.num_rows + 1);
+    } catch (const std::bad_alloc&) {
+        delete c; sa_hip_csv_free(&col);
+        return fail(SA_HIP_ENOMEM, "sa_hip_csv_index_create: out of host memory");
+    }
+    if (col.text_len > 0xFFFFFFFEull) rc = fail(SA_HIP_EINVAL, "sa_hip_csv_index_create: the column exceeds 2^32 - 2 bytes (one index per device)");
+    if (!rc) rc = sa_hip_index_create(&c->idx, col.text_len ? col.text_len : 1, device);
+    if (!rc) rc = sa_hip_index_build(c->idx, col.text, col.text_len, max_suffix_length);
+    if (!rc) rc = sa_hip_index_set_rows(c->idx, col.row_text_starts, col.num_rows);
+    sa_hip_csv_free(&col);
+    if (!rc) rc = csv_index_finish(c);
+    if (rc) { sa_hip_csv_index_destroy(c); return rc; }
+    *out = c;
+    return 0;
+}
+
+int sa_hip_csv_index_adopt(sa_hip_csv_index** out, const char* csv_file, const uint8_t* text, const uint32_t* SA, uint64_t n,
+                           const uint64_t* row_text_starts, const uint64_t* row_file_offsets, uint64_t num_rows,
+                           const char* column_names, uint32_t num_columns, uint32_t column_index, uint32_t max_suffix_length, int device) {
+    if (!out || !csv_file || (!text && n) || (!SA && n) || (num_rows && (!row_text_starts || !row_file_offsets)) || (!column_names && num_columns))
+        return fail(SA_HIP_EINVAL, "sa_hip_csv_index_adopt: NULL argument");
+    *out = nullptr;
+    sa_hip_csv_index* c = nullptr;
+    try {
+        c = new sa_hip_csv_index();
+        c->path = csv_file;
+        c->column_index = column_index;
+        const char* p = column_names;
+        for (u32 i = 0; i < num_columns; ++i) { c->columns.emplace_back(p); p += c->columns.back().size() + 1; }
+        if (num_rows) c->row_file_offsets.assign(row_file_offsets, row_file_offsets + num_rows + 1);
+    } catch (const std::bad_alloc&) { delete c; return fail(SA_HIP_ENOMEM, "sa_hip_csv_index_adopt: out of host memory"); }
+    int rc = sa_hip_index_create(&c->idx, n ? n : 1, device);
+    if (!rc) rc = sa_hip_index_load(c->idx, text, SA, n, max_suffix_length);
+    if (!rc) rc = sa_hip_index_set_rows(c->idx, row_text_starts, num_rows);
+    if (!rc) rc = csv_index_finish(c);
+    if (rc) { sa_hip_csv_index_destroy(c); return rc; }
+    *out = c;
+    return 0;
+}
+
+sa_hip_index* sa_hip_csv_index_handle(sa_hip_csv_index* c) { return c ? c->idx : nullptr; }
+uint64_t sa_hip_csv_index_num_rows(const sa_hip_csv_index* c) { return (c && !c->row_file_offsets.empty()) ? c->row_file_offsets.size() - 1 : 0; }
+uint32_t sa_hip_csv_index_num_columns(const sa_hip_csv_index* c) { return c ? (uint32_t)c->columns.size() : 0; }
+uint32_t sa_hip_csv_index_column_index(const sa_hip_csv_index* c) { return c ? c->column_index : 0; }
+const char* sa_hip_csv_index_column_name(const sa_hip_csv_index* c, uint32_t i) { return (c && i < c->columns.size()) ? c->columns[i].c_str() : nullptr; }
+int sa_hip_csv_index_row_tables(const sa_hip_csv_index* c, const uint64_t** row_text_starts, const uint64_t** row_file_offsets) {
+    if (!c || !c->idx) return fail(SA_HIP_EINVAL, "sa_hip_csv_index_row_tables: NULL index");
+    if (row_text_starts) *row_text_starts = c->idx->row_starts.data();
+    if (row_file_offsets) *row_file_offsets = c->row_file_offsets.data();
+    return 0;
+}
+
+int sa_hip_csv_index_copy_rows(sa_hip_csv_index* c, const uint64_t* row_ids, uint32_t n, char** records) {
+    if (!c || (n && (!row_ids || !records))) return fail(SA_HIP_EINVAL, "sa_hip_csv_index_copy_rows: NULL argument");
+    const u64 rows = sa_hip_csv_index_num_rows(c);
+    for (u32 i = 0; i < n; ++i) records[i] = nullptr;
+    for (u32 i = 0; i < n; ++i) {
+        if (row_ids[i] >= rows) { sa_hip_free_records(records, i); return fail(SA_HIP_EINVAL, "sa_hip_csv_index_copy_rows: no such row"); }
+        records[i] = dup_row(c->map, c->row_file_offsets[row_ids[i]], c->row_file_offsets[row_ids[i] + 1]);
+        if (!records[i]) { sa_hip_free_records(records, i); return fail(SA_HIP_ENOMEM, "sa_hip_csv_index_copy_rows: out of host memory"); }
+    }
+    return 0;
+}
+
+sa_hip_pair_u32 sa_hip_get_substring_positions_file(sa_hip_csv_index* c, const char* substring) {
+    sa_hip_pair_u32 r = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (!c || !c->idx || !substring) { fail(SA_HIP_EINVAL, "sa_hip_get_substring_positions_file: NULL argument"); return r; }
+    u32 nh = 0;
+    sa_hip_pair_u32 q;
+    if (sa_hip_index_query_hits(c->idx, reinterpret_cast<const uint8_t*>(substring), strlen(substring), 0, &q, nullptr, &nh)) return r;
+    // engine.c:962-965: start / end are only ever set on an exact match, so ANY miss is {UINT32_MAX, UINT32_MAX}
+    if (q.first == 0xFFFFFFFFu || (u32)(q.second - q.first + 1u) == 0u) return r;
+    return q;
+}
+
+int sa_hip_get_matching_records_file(sa_hip_csv_index* c, const char* substring, uint32_t k, char** matching_records,
+                                     uint32_t* num_matches) {
+    if (!c || !c->idx || !substring || !num_matches || (!matching_records && k)) return fail(SA_HIP_EINVAL, "sa_hip_get_matching_records_file: NULL argument");
+    if (*num_matches >= k) return 0;   // engine.c:1356: at most k - *num_matches more
+    const u32 want = k - *num_matches;
+    try {
+        std::vector<u64> rows((size_t)want);
+        u32 n = 0;
+        int rc = sa_hip_index_query_rows(c->idx, reinterpret_cast<const uint8_t*>(substring), strlen(substring), want, rows.data(), &n, nullptr);
+        if (rc) return rc;
+        for (u32 i = 0; i < n; ++i) {
+            const u64 r = rows[i];
+            char* s = dup_row(c->map, c->row_file_offsets[r], c->row_file_offsets[r + 1]);
+            if (!s) return fail(SA_HIP_ENOMEM, "sa_hip_get_matching_records_file: out of host memory");
+            matching_records[(*num_matches)++] = s;
+        }
+    } catch (const std::bad_alloc&) { return fail(SA_HIP_ENOMEM, "sa_hip_get_matching_records_file: out of host memory"); }
+    return 0;
+}
+
+uint32_t sa_hip_get_matching_records(const char* str, const sa_hip_SuffixArray_struct* s, const char* substring, uint32_t k,
+                                     char** matching_records) {
+    if (!str || !s || !substring || (!matching_records && k) || (!s->suffix_array && s->n)) { fail(SA_HIP_EINVAL, "sa_hip_get_matching_records: NULL argument"); return 0; }
+    const sa_hip_pair_u32 rg = sa_hip_get_substring_positions(str, s, substring);
+    if (rg.first == 0xFFFFFFFFu || (u32)(rg.second - rg.first + 1u) == 0u) return 0;   // engine.c:1181-1185
+    const u64 n = s->n;
+    u32 made = 0;
+    try {
+        std::unordered_set<u64> seen;
+        for (u64 i = rg.first; i <= (u64)rg.second && made < k; ++i) {
+            const u64 p = s->suffix_array[i];
+            // the record = the text between the newlines around the hit (what engine.c:1187-1211 means to copy)
+            u64 b = p, e = p;
+            while (b > 0 && str[b - 1] != '\n') --b;
+            while (e < n && str[e] != '\n') ++e;
+            if (!seen.insert(b).second) continue;
+            char* r = static_cast<char*>(malloc((size_t)(e - b) + 1));
+            if (!r) { fail(SA_HIP_ENOMEM, "sa_hip_get_matching_records: out of host memory"); return made; }
+            memcpy(r, str + b, (size_t)(e - b));
+            r[e - b] = '\0';
+            matching_records[made++] = r;
+        }
+    } catch (const std::bad_alloc&) { fail(SA_HIP_ENOMEM, "sa_hip_get_matching_records: out of host memory"); }
+    return made;
+}
+
+void sa_hip_free_records(char** records, uint32_t n) {
+    if (!records) return;
+    for (uint32_t i = 0; i < n; ++i) { free(records[i]); records[i] = nullptr; }
+}
+
+// ---- lifecycle mirrors of the seam (engine.c:326-349; pyx:68-74) -------------------------------------------------------
+
+int sa_hip_init_suffix_array_byte_idxs(sa_hip_SuffixArray_struct* s, uint32_t max_suffix_length, uint64_t global_byte_start_idx,
+                                       uint64_t global_byte_end_idx, uint32_t n) {
+    if (!s) return fail(SA_HIP_EINVAL, "sa_hip_init_suffix_array_byte_idxs: NULL argument");
+    s->max_suffix_length = max_suffix_length;
+    s->n = n;
+    s->suffix_array = static_cast<uint32_t*>(malloc((size_t)(n ? n : 1) * sizeof(uint32_t)));
+    s->is_quoted_bitflag = nullptr;   // the row table of sa_hip_csv_index replaces the reference's per-character quoted bits
+    s->global_byte_start_idx = global_byte_start_idx;
+    s->global_byte_end_idx = global_byte_end_idx;
+    if (!s->suffix_array) return fail(SA_HIP_ENOMEM, "sa_hip_init_suffix_array_byte_idxs: out of host memory");
+    return 0;
+}
+
+void sa_hip_free_suffix_array(sa_hip_SuffixArray_struct* s) {
+    if (!s) return;
+    free(s->suffix_array);
+    s->suffix_array = nullptr;
 }
 
 // ---- libsais-call-compatible wrappers --------------------------------------------------------------

@@ -149,3 +149,56 @@ def test_beyond_int32_max_3e9_verified(gpu, monkeypatch):
                     assert bytes(t[int(x):int(x) + 16]) == p
             else:
                 assert bytes(t[int(idx.sa_range(f, 1)[0]):][:16]) > p
+
+
+def test_config5_full_size_csv_mode(gpu, oracle, tmp_path):
+    """BASELINE config 5 at its stated size: 50M-row synthetic company_name CSV (1.5 GB file, 9.16e8 column characters),
+    max_suffix_length = 32, build + query_records.  Checked through size-independent properties: the on-device
+    sufcheck of the truncated order, 200 sampled names whose ranges equal the oracle's binary search over the
+    downloaded SA, whose returned rows all contain the name (at most k, each row once), and -- for 12 of them -- whose
+    hit count equals a memmem count over the extracted column."""
+    import time
+    from suffixarray_amd import SuffixArray
+    from suffixarray_amd.csv_ingest import extract_column
+    rows = 50_000_000
+    path = tmp_path / "companies.csv"
+    gpu.synth_csv(str(path), rows, 1)
+    t0 = time.time()
+    s = SuffixArray(csv_file=str(path), search_column="company_name", max_suffix_length=32)
+    t_index = time.time() - t0
+    idx = s._index
+    st = idx.build_stats()
+    assert idx.verify() == 0, st
+    col = extract_column(str(path), "company_name")
+    text = col.text_array
+    assert idx.n == text.size and len(col.text_row_starts) == rows
+    rng = np.random.default_rng(5)
+    picks = rng.integers(0, rows, 200)
+    starts = col.text_row_starts
+    names = [bytes(text[int(starts[i]):int(starts[i + 1]) - 1 if i + 1 < rows else text.size - 1]) for i in picks]
+    got = s.query_ranges([n.decode().upper() for n in names])   # case-insensitive like the reference (pyx:228)
+    sa = idx.sa_u32()
+    exp = oracle.query_batch(text, sa, 32, names)
+    assert np.array_equal(got["first"], exp["first"]) and np.array_equal(got["second"], exp["second"])
+    del sa
+    hits = (got["second"].astype(np.int64) - got["first"].astype(np.int64) + 1)
+    assert (hits >= 1).all()
+    blob = text.tobytes()
+    for j in range(12):
+        assert blob.count(names[j][:32]) >= 1
+        # occurrences may overlap only for periodic names; count non-overlapping <= hits, and equal for the usual name
+        c = blob.count(names[j][:32])
+        assert c <= hits[j] and (c == hits[j] or len(set(names[j])) < 3), (names[j], c, hits[j])
+    del blob
+    lat = []
+    for n in names[:100]:
+        t0 = time.perf_counter()
+        recs = s.query_records(n.decode(), k=50)
+        lat.append(time.perf_counter() - t0)
+        assert 1 <= len(recs) <= 50
+        assert len({r["id"] for r in recs}) == len(recs)
+        for r in recs:
+            assert n[:32] in r["company_name"].lower().encode(), (n, r)
+    print("config 5: SuffixArray(csv_file) %.2f s, device build %.1f ms, query_records median %.0f us" % (
+        t_index, st["total_ms"], float(np.median(lat)) * 1e6))
+    s.close()

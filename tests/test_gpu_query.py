@@ -118,22 +118,105 @@ def test_python_api_csv(gpu, tmp_path):
     s.close()
 
 
-def test_cython_api_matches_python_mirror(gpu, tmp_path):
+def test_one_python_class_on_the_c_seam(gpu, tmp_path):
+    """suffixarray_amd.SuffixArray IS the Cython class (one implementation; it binds the C seam with `cdef extern`)."""
     from suffixarray_amd.suffix_array import SuffixArray as CySuffixArray
     from suffixarray_amd import SuffixArray
+    assert SuffixArray is CySuffixArray
     docs = ["The quick brown fox jumps over the lazy dog",
             "I am going to the store to buy some milk",
             "Uhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhh"]
-    a, b = CySuffixArray(documents=docs, max_suffix_length=32), SuffixArray(documents=docs, max_suffix_length=32)
-    for q in ("the quick brown fox", "the", "MILK", "zzz", "", "uhh", "o"):
-        assert a.query_records(q) == b.query_records(q), q
+    a = SuffixArray(documents=docs, max_suffix_length=32)
     assert a.query_records("the quick brown fox") == [docs[0]]
-    assert np.array_equal(a.query_ranges(["the", "fox", "zzz"]), b.query_ranges(["the", "fox", "zzz"]))
+    r = a.query_ranges(["the", "fox", "zzz"])
+    assert ((r["second"] - r["first"] + 1) & 0xFFFFFFFF).tolist() == [3, 1, 0]
+    assert a._index.verify() == 0 and a._index.n == len("\n".join(docs))
     p = tmp_path / "c.csv"
     p.write_text('id,company_name,country\n1,Netflix,US\n2,"Acme, Inc.",US\n3,netflix studios,US\n')
-    c = CySuffixArray(csv_file=str(p), search_column="company_name", max_suffix_length=32)
+    c = SuffixArray(csv_file=str(p), search_column="company_name", max_suffix_length=32)
     assert sorted(r["id"] for r in c.query_records("netflix")) == ["1", "3"]
-    a.close(); b.close(); c.close()
+    assert c.query_records("netflix", k=1)[0]["id"] in ("1", "3") and len(c.query_records("netflix", k=1)) == 1
+    assert c.columns == ["id", "company_name", "country"]
+    a.close(); c.close()
+
+
+def test_csv_mode_against_the_reference(gpu, tmp_path):
+    """CSV mode pinned to the reference's own C path (tests/golden/golden_csv.npz, generated by make_golden.py from
+    construct_truncated_suffix_array_from_csv_partitioned_mmap + get_substring_positions_file +
+    get_matching_records_file of the compiled reference): a tiny file with a quoted field and 10 000 rows of the
+    synthetic config-5 generator.  For every pattern without a byte below ',' the C seam's hit count and the row
+    set of query_records equal the reference's; patterns with a space are compared where the reference agrees with
+    a plain scan of the column (its binary search over FILE bytes is not monotone for them, see make_golden.py) and
+    against the scan itself everywhere."""
+    import csv as _csv
+    import io
+    from suffixarray_amd import SuffixArray
+    g = np.load(os.path.join(GOLDEN, "golden_csv.npz"), allow_pickle=False)
+    L = int(g["max_suffix_length"][0])
+    for name in g["names"]:
+        data = bytes(g[f"csv__{name}"])
+        column = str(g[f"column__{name}"][0])
+        path = tmp_path / f"{name}.csv"
+        path.write_bytes(data)
+        rows = list(_csv.reader(io.StringIO(data.decode())))
+        ci = rows[0].index(column)
+        fields = [(int(r[0]), r[ci].lower()) for r in rows[1:]]
+        pats, off, ids = g[f"patterns__{name}"], g[f"row_ids_offsets__{name}"], g[f"row_ids__{name}"]
+        s = SuffixArray(csv_file=str(path), search_column=column, max_suffix_length=L)
+        checked = 0
+        with gpu.CsvIndex(str(path), column, L) as c:
+            assert c.num_rows == len(fields) and c.columns == rows[0]
+            # the reference indexes the header row too (n__ counts its characters); this index does not
+            assert c.index.n == int(g[f"n__{name}"][0]) - (len(column) + 1)
+            for i, p in enumerate(pats):
+                p = str(p)
+                ref_ids = ids[off[i]:off[i + 1]].tolist()
+                scan = sorted(j for j, f in fields if p in f)
+                got = sorted(int(r["id"]) for r in s.query_records(p.upper(), k=len(fields)))
+                assert got == scan, (name, p)
+                first, second = c.get_substring_positions_file(p.encode())
+                assert first != 0xFFFFFFFF
+                hits = sum(f.count(p) if len(p) == 1 else sum(1 for o in range(len(f)) if f.startswith(p, o)) for _, f in fields)
+                assert second - first + 1 == hits, (name, p)
+                if bool(g[f"letters_only__{name}"][i]) or bool(g[f"agrees_with_scan__{name}"][i]):
+                    assert got == ref_ids, (name, p)
+                if bool(g[f"letters_only__{name}"][i]):
+                    assert second - first + 1 == int(g[f"hit_counts__{name}"][i]), (name, p)
+                    checked += 1
+                raw, num = c.get_matching_records_file(p.encode(), len(fields))
+                assert num == len(raw) == len(scan)
+                assert sorted(int(r.split(b",", 1)[0]) for r in raw) == scan
+            # any miss -> {UINT32_MAX, UINT32_MAX} (engine.c:962-965); nothing is appended
+            for miss in (b"zzzzqq", b"company_name", b"\xff"):
+                assert c.get_substring_positions_file(miss) == (0xFFFFFFFF, 0xFFFFFFFF)
+                assert c.get_matching_records_file(miss, 10) == ([], 0)
+        assert checked >= (5 if name == "tiny" else 100)
+        s.close()
+
+
+def test_record_retrieval_seam_conventions(gpu, oracle, tmp_path):
+    """get_matching_records_file's calling convention (engine.c:1326-1390): rows are appended from *num_matches on, at
+    most k in the table overall, every row a malloc'ed string the caller frees; whole rows, each once.  And the
+    in-memory form sa_hip_get_matching_records (engine.c:1168-1215) on a documents text."""
+    p = tmp_path / "c.csv"
+    p.write_bytes(b'id,company_name,country\r\n1,Netflix,US\r\n2,"Acme, Inc.",US\r\n3,netflix netflix studios,US\r\n4,Netflix BV,NL')
+    with gpu.CsvIndex(str(p), "company_name", 32) as c:
+        rows, num = c.get_matching_records_file(b"netflix", 10)
+        assert num == 3 and sorted(rows) == [b"1,Netflix,US", b"3,netflix netflix studios,US", b"4,Netflix BV,NL"]   # row 3 once, no CR / LF
+        rows, num = c.get_matching_records_file(b"netflix", 2)
+        assert num == 2 and len(rows) == 2
+        rows, num = c.get_matching_records_file(b"netflix", 3, already=(b"x", b"y"))   # two slots taken: one more fits
+        assert num == 3 and len(rows) == 1
+        rows, num = c.get_matching_records_file(b"netflix", 2, already=(b"x", b"y"))   # table full
+        assert num == 2 and rows == []
+        assert c.get_matching_records_file(b"acme, inc", 5)[0] == [b'2,"Acme, Inc.",US']
+    docs = [b"the quick brown fox", b"jumps over the lazy dog", b"milk", b"the end"]
+    text = np.frombuffer(b"\n".join(docs), np.uint8)
+    sa = oracle.sais(text).astype(np.uint32)
+    assert sorted(gpu.get_matching_records(text, sa, 32, b"the", 10)) == sorted([docs[0], docs[1], docs[3]])
+    assert gpu.get_matching_records(text, sa, 32, b"the", 1)[0] in (docs[0], docs[1], docs[3])
+    assert gpu.get_matching_records(text, sa, 32, b"milk", 4) == [b"milk"]
+    assert gpu.get_matching_records(text, sa, 32, b"zzz", 4) == []
 
 
 def test_config5_csv_mode_reduced_scale(gpu, tmp_path):

@@ -159,3 +159,51 @@ def test_cython_binding_builds_and_fails_loudly_without_gpu(capi):
         SuffixArray(documents=["a", "b"], max_suffix_length=8)
     with pytest.raises(ValueError):
         SuffixArray(documents=["a"], csv_file="x.csv")
+
+
+def test_lifecycle_mirrors_of_the_seam(capi):
+    """sa_hip_init_suffix_array_byte_idxs / sa_hip_free_suffix_array (engine.c:326-349): host-side malloc / free of the
+    caller's uint32 array, no device involved."""
+    import ctypes as C
+    st = capi.SuffixArrayStruct()
+    assert capi.lib().sa_hip_init_suffix_array_byte_idxs(C.byref(st), 32, 5, 105, 100) == 0
+    assert st.suffix_array and st.n == 100 and st.max_suffix_length == 32
+    assert st.global_byte_start_idx == 5 and st.global_byte_end_idx == 105 and not st.is_quoted_bitflag
+    C.memset(st.suffix_array, 0xAB, 400)   # writable for n entries
+    capi.lib().sa_hip_free_suffix_array(C.byref(st))
+    assert not st.suffix_array
+    capi.lib().sa_hip_free_suffix_array(C.byref(st))   # idempotent
+    assert capi.lib().sa_hip_init_suffix_array_byte_idxs(None, 32, 0, 0, 1) == -1
+
+
+def test_csv_extractor_against_reference_row_sets(capi, tmp_path):
+    """The native column extractor pinned to the reference's CSV builder: on the files of
+    tests/golden/golden_csv.npz the rows whose extracted field contains a pattern, and the number of occurrences,
+    equal what the compiled reference returned (get_substring_positions_file / get_matching_records_file over
+    construct_truncated_suffix_array_from_csv_partitioned_mmap) for every pattern without a byte below ','."""
+    import os
+    from conftest import GOLDEN
+    from suffixarray_amd.csv_ingest import extract_column
+    g = np.load(os.path.join(GOLDEN, "golden_csv.npz"), allow_pickle=False)
+    for name in g["names"]:
+        data = bytes(g[f"csv__{name}"])
+        column = str(g[f"column__{name}"][0])
+        path = tmp_path / f"{name}.csv"
+        path.write_bytes(data)
+        col = extract_column(str(path), column)
+        fields = col.text.split(b"\n")[:-1]
+        # the reference's text = ours + the header row's field (it indexes the header like a record)
+        assert len(col.text) == int(g[f"n__{name}"][0]) - (len(column) + 1)
+        ids = [int(data[int(a):int(b)].split(b",", 1)[0]) for a, b in zip(col.row_file_offsets[:-1], col.row_file_offsets[1:])]
+        pats, off, rid = g[f"patterns__{name}"], g[f"row_ids_offsets__{name}"], g[f"row_ids__{name}"]
+        n_checked = 0
+        for i, p in enumerate(pats):
+            if not bool(g[f"letters_only__{name}"][i]):
+                continue
+            pb = str(p).encode()
+            rows = sorted(j for j, f in zip(ids, fields) if pb in f)
+            occ = sum(sum(1 for o in range(len(f)) if f.startswith(pb, o)) for f in fields)
+            assert rows == rid[off[i]:off[i + 1]].tolist(), (name, p)
+            assert occ == int(g[f"hit_counts__{name}"][i]) == int(g[f"record_counts__{name}"][i]), (name, p)
+            n_checked += 1
+        assert n_checked >= 5
