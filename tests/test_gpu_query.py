@@ -128,8 +128,9 @@ def test_one_python_class_on_the_c_seam(gpu, tmp_path):
             "Uhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhh"]
     a = SuffixArray(documents=docs, max_suffix_length=32)
     assert a.query_records("the quick brown fox") == [docs[0]]
-    r = a.query_ranges(["the", "fox", "zzz"])
-    assert ((r["second"] - r["first"] + 1) & 0xFFFFFFFF).tolist() == [3, 1, 0]
+    r = a.query_ranges(["the", "fox", "qqq", "zzz"])
+    assert ((r["second"] - r["first"] + 1) & 0xFFFFFFFF).tolist()[:3] == [3, 1, 0]
+    assert (int(r["first"][3]), int(r["second"][3])) == (0xFFFFFFFF, 0xFFFFFFFF)   # every suffix is smaller (engine.c:896-898)
     assert a._index.verify() == 0 and a._index.n == len("\n".join(docs))
     p = tmp_path / "c.csv"
     p.write_text('id,company_name,country\n1,Netflix,US\n2,"Acme, Inc.",US\n3,netflix studios,US\n')
