@@ -985,6 +985,7 @@ struct Builder {
     CodeMap qmap;
     int q_b = 0, q_k0 = 0, q_dbits = 0;
     bool dir_ready = false;   // the directory in qdir belongs to qkeys
+    bool sector_search = true;    // SA_HIP_SECTOR_SEARCH: interpolated sector scan inside a directory bucket (sa_query.hpp)
 
     // Characters in the initial key.  Enough that, for an i.i.d. text with this byte
     // distribution, about 2 % of the suffixes still share their key (collision probability
@@ -1038,6 +1039,7 @@ struct Builder {
         if (const char* e = getenv("SA_HIP_LOCAL_ROUNDS")) local_rounds = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_GROUP_FINISH")) group_finish = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_PILOT")) use_pilot = atoi(e) != 0;
+        if (const char* e = getenv("SA_HIP_SECTOR_SEARCH")) sector_search = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_FIN_COUNT_MAX")) fin_count_max = (u32)atoi(e);
         if (const char* e = getenv("SA_HIP_FIN_RADIX_CHARS")) fin_radix_chars = atoi(e);
         if (const char* e = getenv("SA_HIP_DEBUG_ROUNDS")) debug_rounds = atoi(e) != 0;
@@ -1053,8 +1055,8 @@ struct Builder {
     int ensure_build_buffers() {
         const u64 cap = n_max ? n_max : 1;
         int rc;
-        if ((rc = keys0.ensure(cap * 8))) return rc;
-        if ((rc = keys1.ensure(cap * 8))) return rc;
+        if ((rc = keys0.ensure(cap * 8 + 64))) return rc;   // (+ one sector: the query path reads whole 64-byte sectors of the key array)
+        if ((rc = keys1.ensure(cap * 8 + 64))) return rc;
         if ((rc = vals0.ensure(cap * 4))) return rc;
         if ((rc = vals1.ensure(cap * 4))) return rc;
         if ((rc = flags.ensure(cap + 64))) return rc;
@@ -1279,7 +1281,7 @@ struct Builder {
         dir_ready = false;
         if (n < 2) return 0;
         const int k0 = choose_initial_chars(b, L);
-        int rc = keys0.ensure((size_t)n * 8);
+        int rc = keys0.ensure((size_t)n * 8 + 64);
         if (rc) return rc;
         hipLaunchKernelGGL(gather_keys_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, stream, text.as<u8>(), n, map, b, k0,
                            (const u32*)sa, keys0.as<u64>());

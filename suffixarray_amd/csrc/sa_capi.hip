@@ -65,6 +65,7 @@ int launch_query(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q
     a.keys = idx->b.qkeys;
     a.keys32 = idx->b.qkeys32;
     a.lo_shift = idx->b.q_lo_shift;
+    a.sector_search = idx->b.sector_search ? 1 : 0;
     a.dir = idx->b.qdir.as<u32>();
     a.b = idx->b.q_b; a.k0 = idx->b.q_k0; a.dbits = idx->b.q_dbits;
     SA_HIP_CHECK(hipEventRecord(idx->q_begin, idx->stream));

@@ -94,7 +94,71 @@ struct QueryArgs {
     int b, k0, dbits;
     const u32* keys32;      // NARROW: K[j] = (top digit of j's directory bucket << 56) | (keys32[j] << lo_shift)
     int lo_shift;
+    int sector_search;      // 1: interpolated sector scan inside the directory bucket (below); 0: plain binary search
 };
+
+// The batch is bound by the NUMBER of 64-byte sectors it requests, not by bytes or by the dependent-load chain
+// (profiles/r02_a_pmc_*: 5.5 requests per query at the ~36 G requests/s the memory system sustains for random reads,
+// tools/gatherbench).  A binary search over the ~35 slots of a directory bucket touches 2-3 sectors of K.  The keys of
+// a bucket are close to uniformly spread over the bucket's key interval, so the place of a key is first ESTIMATED by
+// linear interpolation and the whole sector around it is read (one request: the lane's four 16-byte loads hit the line
+// the first one brings in); sorted keys tell at once whether the bound lies inside, to the left or to the right.
+// Returns the first slot in [l, h) whose key is >= t (h if none).  win / wbase: the keys of the sector the answer was
+// found in and the slot of win[0] (for the upper bound, which usually lies in the same sector).
+template <typename KT>
+struct SectorWindow {
+    static constexpr int W = 64 / (int)sizeof(KT);
+    KT k[W];
+    u64 base;    // slot of k[0] (a multiple of W)
+};
+template <typename KT>
+__device__ __forceinline__ void load_sector(const KT* __restrict__ K, u64 base, SectorWindow<KT>& w) {
+    w.base = base;
+    const uint4* p = reinterpret_cast<const uint4*>(K + base);   // K is 256-byte aligned and padded to whole sectors
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint4 v = p[i];
+        if (sizeof(KT) == 4) { w.k[4 * i] = (KT)v.x; w.k[4 * i + 1] = (KT)v.y; w.k[4 * i + 2] = (KT)v.z; w.k[4 * i + 3] = (KT)v.w; }
+        else { w.k[2 * i] = (KT)(((u64)v.y << 32) | v.x); w.k[2 * i + 1] = (KT)(((u64)v.w << 32) | v.z); }
+    }
+}
+// first slot in [l, h) with key >= t (STRICT: > t), starting at the sector of `est`; l < h
+template <bool STRICT, typename KT>
+__device__ __forceinline__ u64 sector_bound(const KT* __restrict__ K, u64 l, u64 h, KT t, u64 est, SectorWindow<KT>& w, bool have_window) {
+    constexpr int W = SectorWindow<KT>::W;
+    u64 lo = l, hi = h;   // the bound lies in [lo, hi]
+    u64 base = est & ~(u64)(W - 1);
+    for (int step = 0; step < 3 && lo < hi; ++step) {
+        if (!(have_window && w.base == base)) load_sector(K, base, w);
+        have_window = false;
+        // slots of this sector inside [lo, hi)
+        const u64 a = base > lo ? base : lo;
+        const u64 b = (base + W < hi) ? base + W : hi;
+        u32 below = 0;   // keys of [a, b) that are < t (<= t)
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const u64 slot = base + i;
+            const bool in = slot >= a && slot < b;
+            const bool less = STRICT ? (w.k[i] <= t) : (w.k[i] < t);
+            below += (in && less) ? 1u : 0u;
+        }
+        if (below == 0) {             // every key here is >= t: the bound is a or further left
+            hi = a;
+            if (a == lo) break;
+            base -= W;                // (a > lo: a == base, the sector before exists)
+        } else if (below == (u32)(b - a)) {   // every key here is < t: further right
+            lo = b;
+            if (b == hi) break;
+            base += W;
+        } else { lo = hi = a + below; }
+    }
+    while (lo < hi) {   // rare: the estimate was more than two sectors off (long runs of equal keys, lumpy buckets)
+        const u64 mid = (lo + hi) >> 1;
+        const KT k = K[mid];
+        if (STRICT ? (k <= t) : (k < t)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
 
 template <bool NARROW>
 __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
@@ -141,6 +205,7 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
                 // bits below them, and "K > key_hi" can only hold when key_hi has the same top digit; the bits
                 // below lo_shift are zero in K and in key_lo and all ones in key_hi (sh >= lo_shift).
                 KT t_lo, t_hi1, t_hi2;
+                bool searched = false;
                 if (NARROW) {
                     // the stored form is (u32)(key >> lo_shift): keys of 40 bits lose their top digit in the
                     // truncation, shorter ones keep (part of) it -- the thresholds are truncated the same way
@@ -148,13 +213,31 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
                     t_hi2 = (KT)(key_hi >> a.lo_shift);
                     t_hi1 = ((key_lo >> 56) == (key_hi >> 56)) ? t_hi2 : (KT)~(KT)0;
                 } else { t_lo = (KT)key_lo; t_hi1 = t_hi2 = (KT)key_hi; }
+                if (a.sector_search && bh == bl && l < h) {
+                    // one bucket: its keys lie in [bkt << ds, (bkt + 1) << ds); estimate the place of key_lo by its
+                    // position in that interval (stored form: bits below the bucket bits, above lo_shift)
+                    const int vs = NARROW ? a.lo_shift : 0;                         // low bit of the stored form
+                    const int sb = ds - vs;                                         // stored bits below the bucket bits
+                    u64 est = l;
+                    if (sb > 0) {
+                        const u64 frac = (key_lo >> vs) & ((1ull << sb) - 1ull);    // position inside the bucket's interval
+                        const int down = sb > 20 ? sb - 20 : 0;                     // 20 significant bits are plenty for <= 2^20 slots
+                        est = l + (((frac >> down) * (h - l)) >> (sb - down));
+                        if (est >= h) est = h - 1;
+                    }
+                    SectorWindow<KT> w;
+                    lo = sector_bound<false>(K, l, h, t_lo, est, w, false);
+                    hi = (lo < h) ? sector_bound<true>(K, lo, h, t_hi2, lo, w, true) : lo;
+                    searched = true;
+                }
                 // first slot with K >= key_lo
-                while (l < h) {
+                while (!searched && l < h) {
                     const u64 mid = (l + h) >> 1;
                     const KT k = K[mid];
                     if (k < t_lo) l = mid + 1;
                     else { h = mid; if (k > t_hi1) h_strict = mid; }
                 }
+                if (!searched) {
                 lo = l;
                 // first slot with K > key_hi, inside [max(lo, dir[bh]), h_strict]
                 u64 l2 = (bh == bl) ? lo : (h2_lo > lo ? h2_lo : lo);
@@ -164,6 +247,7 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
                     if (K[mid] <= t_hi2) l2 = mid + 1; else h2 = mid;
                 }
                 hi = l2;
+                }
                 exact = ((u32)P == c);
             }
         }

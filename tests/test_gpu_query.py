@@ -372,3 +372,41 @@ def test_narrow_key_array_matches_wide_key_array(gpu, oracle, monkeypatch):
         assert np.array_equal(got["1"], got["0"]), (t.size, k0, L)
         exp = oracle.query_batch(t, sas["1"], L if L else 0xFFFFFFFF, pats)
         assert np.array_equal(got["1"], exp), (t.size, k0, L)
+
+
+def test_sector_search_matches_binary_search(gpu, oracle, monkeypatch):
+    """Inside a directory bucket the key search is an interpolated scan of whole 64-byte sectors (sa_query.hpp:
+    sector_bound; default) instead of a binary search (SA_HIP_SECTOR_SEARCH=0): identical ranges, equal to the oracle's
+    (engine.c:869-918), for narrow (u32) and wide (u64) key arrays, adopted indexes (keys gathered from the text), a
+    skewed alphabet (buckets of very different sizes, long runs of equal keys: the estimate is far off and the scan falls
+    back to bisection), word text (equal keys in the thousands), texts shorter than a sector, truncated indexes."""
+    from suffixarray_amd import synth
+    rng = np.random.default_rng(99)
+    skew = rng.choice(np.array([97, 98, 99, 100, 122], dtype=np.uint8), 5_000_000, p=[0.9, 0.04, 0.03, 0.02, 0.01])
+    st = cases.small_texts()
+    runs = [("d1", synth.d1_uniform27(4_600_003), 0, {}), ("d1_wide", synth.d1_uniform27(4_600_003), 0, {"SA_HIP_NARROW_K": "0"}),
+            ("d1_L12", synth.d1_uniform27(4_500_000), 12, {}), ("skew", skew, 0, {}), ("skew_k5", skew, 0, {"SA_HIP_INITIAL_CHARS": "5"}),
+            ("words", synth.d2_words(5_000_000), 0, {}), ("words_narrow", synth.d2_words(5_000_000), 0, {"SA_HIP_PILOT": "0"}),
+            ("banana", st["banana"], 0, {}), ("r27_63", st["r27_63"], 0, {}), ("all_a_5000", st["all_a_5000"], 0, {}),
+            ("d2_300k", st["d2_300k"], 0, {}), ("d2_300k_L7", st["d2_300k"], 7, {})]
+    for name, t, L, env in runs:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pats = cases.query_patterns(t, 4000, rng)
+        pats += [bytes([c]) for c in np.unique(t)[:8]] + [bytes(t[p:p + m]) for p in (0, max(t.size - 9, 0)) for m in (1, 2, 3, 8, 9, 16)]
+        got = {}
+        sa = None
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SA_HIP_SECTOR_SEARCH", mode)
+            with gpu.DeviceIndex(t.size, 0) as idx:
+                idx.build(t, L)
+                sa = idx.sa_u32().copy()
+                got[mode] = idx.query_batch(pats)
+                idx.load(t, sa, L)           # adopted: u64 keys gathered from the text, directory by binary search
+                got[mode + "_adopted"] = idx.query_batch(pats)
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        exp = oracle.query_batch(t, sa, L if L else 0xFFFFFFFF, pats)
+        for k, v in got.items():
+            assert np.array_equal(v, exp), (name, k)
+    monkeypatch.delenv("SA_HIP_SECTOR_SEARCH", raising=False)
