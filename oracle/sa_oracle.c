@@ -20,7 +20,7 @@
  *
  * Pinning: the reference holds no golden vectors for this path, so this
  * restatement is pinned against the reference itself compiled in place (oracle/_ref,
- * see oracle/Makefile) by tests/test_oracle_vs_ref.py, and against fixtures generated
+ * see oracle/Makefile) by tests/test_oracle.py, and against fixtures generated
  * from that build (tests/golden/, generator tests/golden/make_golden.py).
  */
 #include <stdint.h>

@@ -191,7 +191,8 @@ __device__ __forceinline__ void dir_emit(const DirArgs& d, u32 first, u32 last, 
 }
 
 // The directory is written early in the build; reading it once at the end leaves its 2^dbits * 4 bytes
-// (<= 64 MB) in the memory-side cache for the first query batch, as a directory built last would be.
+// (268 MB at the default 26 bits for n = 1e9, 4 MB at n = 1e7) in the memory-side cache for the first query batch
+// as far as they fit, as a directory built last would be.
 __global__ __launch_bounds__(256) void dir_touch_kernel(const uint4* __restrict__ dir16, u64 n16, u32* __restrict__ sink) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     u32 acc = 0;
@@ -1052,11 +1053,17 @@ struct Builder {
         memset(freq, 0, sizeof freq);
         return 0;
     }
+    // the ping-pong key buffers: u64[n] for the 12-byte-record plan, u32[n] when the sort runs on narrow records (8 GB less
+    // at n = 1e9); + one sector: the query path reads whole 64-byte sectors of the key array
+    int ensure_key_buffers(u64 count, bool narrow) {
+        const size_t bytes = (size_t)(count ? count : 1) * (narrow ? 4 : 8) + 64;
+        int rc;
+        if ((rc = keys0.ensure(bytes))) return rc;
+        return keys1.ensure(bytes);
+    }
     int ensure_build_buffers() {
         const u64 cap = n_max ? n_max : 1;
         int rc;
-        if ((rc = keys0.ensure(cap * 8 + 64))) return rc;   // (+ one sector: the query path reads whole 64-byte sectors of the key array)
-        if ((rc = keys1.ensure(cap * 8 + 64))) return rc;
         if ((rc = vals0.ensure(cap * 4))) return rc;
         if ((rc = vals1.ensure(cap * 4))) return rc;
         if ((rc = flags.ensure(cap + 64))) return rc;
@@ -1481,6 +1488,8 @@ struct Builder {
         // pass reads the text itself, key generation shrinks to the histogram of that digit
         const bool text_pass = narrow_path && text_top_pass && text_pass_applies(b, k0);
         stats.text_top_pass = text_pass ? 1u : 0u;
+        // (a narrow sort fed from a u64 key array -- no text pass -- needs the wide buffers for that array)
+        if ((rc = ensure_key_buffers(n, narrow_path && text_pass && narrow_k && fuse_directory))) return rc;
         if (text_pass) {
             if ((rc = narrow_text_histogram(radix, narrow, stream, text.as<u8>(), map, n32, b))) return rc;
         } else {
