@@ -969,6 +969,7 @@ struct Builder {
         else { u32* t = lst_cur; lst_cur = lst_nxt; lst_nxt = t; }
         lst_first = false;
     }
+    int big_round_chars = 0;             // SA_HIP_BIG_ROUND_CHARS: characters per global round while the finisher is at work (0 = as many as fit; 3..7 measured: no gain, tools/gpu_bigchars_sweep.py)
     u32 fin_count_max = FIN_COUNT_MAX;   // SA_HIP_FIN_COUNT_MAX
     int fin_radix_chars = FIN_RADIX_CHARS;   // SA_HIP_FIN_RADIX_CHARS
     u64 local_records = 0, big_records = 0;   // of the last build: records sorted in LDS / through the big-group list
@@ -1042,6 +1043,7 @@ struct Builder {
         if (const char* e = getenv("SA_HIP_PILOT")) use_pilot = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_SECTOR_SEARCH")) sector_search = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_FIN_COUNT_MAX")) fin_count_max = (u32)atoi(e);
+        if (const char* e = getenv("SA_HIP_BIG_ROUND_CHARS")) big_round_chars = atoi(e);
         if (const char* e = getenv("SA_HIP_FIN_RADIX_CHARS")) fin_radix_chars = atoi(e);
         if (const char* e = getenv("SA_HIP_DEBUG_ROUNDS")) debug_rounds = atoi(e) != 0;
         if (debug_rounds) { radix.debug_hook = &Builder::sort_debug_hook; radix.debug_ctx = this; }
@@ -1585,9 +1587,11 @@ struct Builder {
         while (M && (L == 0 || h < L)) {
             // groups that fit a tile are finished in LDS, whatever their number of rounds; the global round below is for
             // the rest (an average group of more than half a tile: hardly anything fits)
+            bool finisher_ran = false;
             if (group_finish && fin_useful && !have_isa && (u64)M <= (u64)G * (FIN_CAP / 2)) {
                 if ((rc = run_group_finisher(map, b, L, h, M, G, tot))) return rc;
                 if (!M) break;
+                finisher_ran = fin_useful;
             }
             const int gb = bits_for(G);
             // Chunk rounds read the next characters from the text; doubling rounds need the inverse suffix array
@@ -1600,6 +1604,9 @@ struct Builder {
             int kc = 0;
             if (use_chunk) {
                 kc = (64 - gb) / b;
+                // what the finisher left are groups too large for a tile: a few characters take them apart far enough for
+                // the next finisher run, and every 8 key bits less is a pass less over their records
+                if (finisher_ran && big_round_chars > 0 && kc > big_round_chars) kc = big_round_chars;
                 if (L && (u64)kc > L - h) kc = (int)(L - h);
                 if (kc <= 0) use_chunk = false;
             }

@@ -1,6 +1,8 @@
-"""Randomized soak of the tile-local round sort (round_sort.hpp): texts made of repeated, mutated segments over random
-alphabets -- groups of every size, long common prefixes, chunk and doubling rounds, truncation depths -- built with
-SA_HIP_LOCAL_ROUNDS = 1 and 0: identical suffix arrays, each verified on the device."""
+"""Randomized soak of the refinement machinery (group_finish.hpp, round_sort.hpp): texts made of repeated, mutated segments
+over random alphabets -- groups of every size, long common prefixes, chunk and doubling rounds, truncation depths -- built
+with the in-LDS group finisher on and off and the tile-local round sort on and off (SA_HIP_GROUP_FINISH x
+SA_HIP_LOCAL_ROUNDS), with random initial key lengths: identical suffix arrays, each verified on the device.
+    python3 tools/gpu_round_soak.py [seed] [cases]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,16 +34,22 @@ for c in range(cases):
     t = np.concatenate(parts)[:n]
     L = int(rng.choice([0, 0, 0, 9, 40, 200]))
     res = {}
-    for mode in ("1", "0"):
-        os.environ["SA_HIP_LOCAL_ROUNDS"] = mode
+    k0 = int(rng.choice([0, 0, 2, 4, 7]))
+    if k0:
+        os.environ["SA_HIP_INITIAL_CHARS"] = str(k0)
+    else:
+        os.environ.pop("SA_HIP_INITIAL_CHARS", None)
+    for mode in ("11", "10", "01", "00"):
+        os.environ["SA_HIP_GROUP_FINISH"] = mode[0]
+        os.environ["SA_HIP_LOCAL_ROUNDS"] = mode[1]
         with _capi.DeviceIndex(n, 0) as idx:
             idx.build(t, L)
             res[mode] = (idx.sa_u32().copy(), idx.verify(), idx.build_stats())
-    ok = np.array_equal(res["1"][0], res["0"][0]) and res["1"][1] == 0 and res["0"][1] == 0
+    ok = all(np.array_equal(res["11"][0], res[m][0]) and res[m][1] == 0 for m in res)
     bad += not ok
-    s1, s0 = res["1"][2], res["0"][2]
-    print("case %2d sigma %3d n %7d seg %6d L %3d rounds %2d (chunk %d dbl %d) global passes %3d vs %3d -> %s" % (
-        c, sigma, n, seg_len, L, s1["rounds"], s1["chunk_rounds"], s1["doubling_rounds"], s1["radix_passes"], s0["radix_passes"],
-        "ok" if ok else "MISMATCH"), flush=True)
+    s1, s0 = res["11"][2], res["00"][2]
+    print("case %2d sigma %3d n %7d seg %6d L %3d k0 %d: finisher resolved %8d of %8d looked at in %d runs; rounds %2d vs %2d (dbl %d vs %d) -> %s" % (
+        c, sigma, n, seg_len, L, k0, s1["finisher_resolved"], s1["finisher_records"], s1["finisher_runs"], s1["rounds"], s0["rounds"],
+        s1["doubling_rounds"], s0["doubling_rounds"], "ok" if ok else "MISMATCH"), flush=True)
 print("FAILED %d" % bad if bad else "ALL OK")
 sys.exit(1 if bad else 0)
