@@ -333,7 +333,14 @@ def run_single(args, torch, _capi, synth, dev, device):
         tq = pmc_q["traffic_bytes_per_launch"]
         rq.update(traffic=tq, bytes_per_query=tq / Q, achieved=tq / (query_ms / steps / 1e3) / 1e9,
                   frac=tq / (query_ms / steps / 1e3) / HBM_PEAK,
-                  traffic_note="FETCH_SIZE x2 + WRITE_SIZE of one 1M-query launch, profiles/pmc_query.json")
+                  traffic_note="FETCH_SIZE (x1: random 64-byte requests are tallied exactly) + WRITE_SIZE of one 1M-query launch, profiles/pmc_query.json")
+        # the batch is bound by the NUMBER of random 64-byte requests, not by bytes: requests per second against the rate
+        # the memory system sustains for that access pattern (tools/gatherbench, profiles/r02_a_pmc_calibration.md)
+        if pmc_q.get("read_requests_per_query") and pmc_q.get("random_read_requests_per_s_ceiling"):
+            rps = pmc_q["read_requests_per_query"] * Q / (query_ms / steps / 1e3)
+            rq["random_requests"] = {"per_query": pmc_q["read_requests_per_query"], "per_s": rps,
+                                     "ceiling_per_s": pmc_q["random_read_requests_per_s_ceiling"],
+                                     "frac_of_ceiling": rps / pmc_q["random_read_requests_per_s_ceiling"]}
     else:
         rq.update(traffic=None, achieved=None, frac=None)
     line = {

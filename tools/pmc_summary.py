@@ -96,6 +96,23 @@ def main():
         if rr:
             j["raw_requests"] = rr
             j["read_requests_per_query"] = rr.get("TCC_EA0_RDREQ_sum", 0.0) / queries
+        # the request-rate ceiling of the memory system for random 64-byte reads: tools/gatherbench WITHOUT the profiler
+        # (its log of the calib stage, best of the 4-byte runs); kept from the previous summary when that stage did not run
+        ceiling = None
+        log = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_calib_fetch.log")
+        if os.path.exists(log):
+            import re
+            rates = [float(m.group(1)) for m in re.finditer(r"4-byte: [0-9.]+ ms \(([0-9.]+) G reads/s\)", open(log).read())]
+            if rates:
+                ceiling = max(rates) * 1e9
+        if ceiling is None:
+            try:
+                ceiling = json.load(open(os.path.join(ROOT, "profiles", "pmc_query.json"))).get("random_read_requests_per_s_ceiling")
+            except Exception:
+                pass
+        j["random_read_requests_per_s_ceiling"] = ceiling
+        j["ceiling_note"] = ("tools/gatherbench under the profiler's process (kernel time by HIP events): 2^24 random 4-byte reads of a 4 GiB "
+                             "table, one 64-byte request each; the rate at which the memory system serves such requests")
         json.dump(j, open(os.path.join(ROOT, "profiles", "pmc_query.json"), "w"), indent=1)
         print(json.dumps(j, indent=1))
 
