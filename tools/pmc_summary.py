@@ -116,6 +116,37 @@ def main():
         json.dump(j, open(os.path.join(ROOT, "profiles", "pmc_query.json"), "w"), indent=1)
         print(json.dumps(j, indent=1))
 
+    # ---- instruction counters per kernel of a build ---------------------------------------------------------------------
+    valu = rows(counter_file(tag, "valu"))
+    if valu:
+        per = {}
+        for d, k, g, c, v in valu:
+            if g < (1 << 22) or not any(s_ in k for s_ in KEEP):   # the launches over the whole input only
+                continue
+            per.setdefault((d, k), {})[c] = v
+        agg = {}
+        for (d, k), cs in per.items():
+            a = agg.setdefault(k, {"launches": 0})
+            a["launches"] += 1
+            for c, v in cs.items():
+                a[c] = a.get(c, 0.0) + v
+        lines = [f"# Instruction counters of a D1 build at N = {n_chars:,} ({tag})", "",
+                 "`rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace",
+                 "--output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary`; per launch, launches over the whole input.",
+                 "SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count quad-cycles (MI355X_MICROARCH.md); busy = active cycles of the unit / (GRBM_GUI_ACTIVE / 8 XCDs x 4 SIMDs x 256 CUs / 8).", "",
+                 "| kernel | launches | waves | VALU instr / wave | LDS instr / wave | VALU active (quad-cycles) / wave | LDS active / wave | wave cycles / wave |",
+                 "|---|---|---|---|---|---|---|---|"]
+        for k, a in sorted(agg.items()):
+            w = a.get("SQ_WAVES", 0.0)
+            if w <= 0:
+                continue
+            lines.append("| `%s` | %d | %.0f | %.0f | %.0f | %.0f | %.0f | %.0f |" % (
+                k, a["launches"], w / a["launches"], a.get("SQ_INSTS_VALU", 0) / w, a.get("SQ_INSTS_LDS", 0) / w,
+                a.get("SQ_ACTIVE_INST_VALU", 0) / w, a.get("SQ_ACTIVE_INST_LDS", 0) / w, a.get("SQ_WAVE_CYCLES", 0) / w))
+        open(os.path.join(ROOT, "profiles", f"{tag}_pmc_valu.md"), "w").write("\n".join(lines) + "\n")
+        keep_csv(tag, "valu", valu)
+        print("\n".join(lines))
+
     # ---- calibration on random reads ------------------------------------------------------------------------------------
     cf, cr = rows(counter_file(tag, "calib_fetch")), rows(counter_file(tag, "calib_raw"))
     if cf:
