@@ -442,13 +442,19 @@ def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
     broadcast_index(tx_t, sa_t, src=0)
     barrier()
     bcast_ms = (time.perf_counter() - b0) * 1e3
-    if rank != 0:
+    searcher = idx
+    if rank != 0 or args.exercise_dist:
+        # adopts the replica: key array + directory, no construction.  (--exercise-dist: rank 0 too answers from an adopted
+        # copy of its own index, so that a single GPU runs every line a non-building rank runs.)
+        if rank == 0:
+            searcher = _capi.DeviceIndex(N, local_rank)
         t0 = time.perf_counter()
-        idx.load_device(tx_t.data_ptr(), sa_t.data_ptr(), N, 0)    # adopts the replica: key array + directory, no construction
+        searcher.load_device(tx_t.data_ptr(), sa_t.data_ptr(), N, 0)
+        searcher.sync()
         adopt_ms = (time.perf_counter() - t0) * 1e3
-        del tx_t, sa_t
     else:
         adopt_ms = 0.0
+    del tx_t, sa_t
 
     # ONE global batch, the same on every rank; this rank's slice goes to its GPU
     lo, hi = shard_bounds(Qg, world, rank)
@@ -456,8 +462,8 @@ def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
     batch = ShardedBatch(q_buf, q_off, Qg, world, rank, dev)
 
     def search(pat_t, off_t, q_local, out_t):
-        idx.query_batch_device(pat_t.data_ptr(), off_t.data_ptr(), q_local, out_t.data_ptr())
-        idx.sync()   # the index has its own stream; the gather runs on torch's
+        searcher.query_batch_device(pat_t.data_ptr(), off_t.data_ptr(), q_local, out_t.data_ptr())
+        searcher.sync()   # the index has its own stream; the gather runs on torch's
 
     for _ in range(args.warmup):
         batch.step(search)
@@ -466,7 +472,7 @@ def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         batch.step(search)
-        kern_ms += idx.query_stats()["kernel_ms"]
+        kern_ms += searcher.query_stats()["kernel_ms"]
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt, kern_ms, adopt_ms], dtype=torch.float64, device=dev)
@@ -513,6 +519,8 @@ def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
             "adopt_ms_max_rank": adopt_ms_max,
             "gate": gate,
         }
+    if searcher is not idx:
+        searcher.close()
     idx.close()
     return line
 

@@ -207,3 +207,31 @@ def test_csv_extractor_against_reference_row_sets(capi, tmp_path):
             assert occ == int(g[f"hit_counts__{name}"][i]) == int(g[f"record_counts__{name}"][i]), (name, p)
             n_checked += 1
         assert n_checked >= 5
+
+
+def test_record_seam_argument_validation(capi, tmp_path):
+    """The record-retrieval entry points return codes instead of crashing or exiting (the reference printf()s and
+    exit(1)s: engine.c:1334-1338, 475-483): NULL arguments, a missing file, an unknown column -- all without a device."""
+    import ctypes as C
+    L = capi.lib()
+    h = C.c_void_p()
+    assert L.sa_hip_csv_index_create(C.byref(h), b"/nonexistent/file.csv", b"name", 32, 0) == -1 and not h
+    assert b"cannot open" in L.sa_hip_last_error()
+    p = tmp_path / "t.csv"
+    p.write_bytes(b"id,name\n1,abc\n")
+    assert L.sa_hip_csv_index_create(C.byref(h), str(p).encode(), b"nope", 32, 0) == -1 and not h
+    assert b"column not found" in L.sa_hip_last_error()
+    assert L.sa_hip_csv_index_create(C.byref(h), str(p).encode(), b"name", 0, 0) == -1          # max_suffix_length must be >= 1
+    assert L.sa_hip_csv_index_create(None, str(p).encode(), b"name", 32, 0) == -1
+    n = C.c_uint32(0)
+    assert L.sa_hip_get_matching_records_file(None, b"x", 4, None, C.byref(n)) == -1
+    r = L.sa_hip_get_substring_positions_file(None, b"x")
+    assert (r.first, r.second) == (0xFFFFFFFF, 0xFFFFFFFF)
+    assert L.sa_hip_index_set_rows(None, None, 0) == -1
+    assert L.sa_hip_index_query_rows(None, b"x", 1, 4, None, C.byref(n), None) == -1
+    assert L.sa_hip_csv_index_num_rows(None) == 0 and L.sa_hip_csv_index_num_columns(None) == 0
+    assert L.sa_hip_csv_index_column_name(None, 0) is None
+    L.sa_hip_csv_index_destroy(None)   # no-op
+    L.sa_hip_free_records(None, 3)     # no-op
+    tab = (C.c_void_p * 2)()
+    assert L.sa_hip_get_matching_records(None, None, b"x", 2, tab) == 0
