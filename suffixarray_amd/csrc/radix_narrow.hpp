@@ -380,9 +380,12 @@ __global__ __launch_bounds__(BLOCK, (ITEMS > 16) ? 4 : (LATEV ? 6 : 4)) void seg
 // thread owns 16 consecutive positions (one 16-byte load + the next one for the c8 - 1 characters that
 // follow), rolls a c8-character window over them and counts into one of TOP_HIST_COPIES LDS histograms.
 constexpr int TOP_HIST_COPIES = 8;
+// LOW_K0 > 0: the histogram of the LOWEST 8 key bits instead (pass 0 of the plain LSD sort of LOW_K0-character keys,
+// text_low_pass_kernel): those are the low bits of the key's last c8 characters, i.e. the same rolling window LOW_K0 - c8
+// characters further on.
 template <int C8>   // characters that make up the top 8 key bits: ceil(8 / b), a compile-time constant so that the window loop unrolls
 __global__ __launch_bounds__(256) void top_hist_kernel(const u8* __restrict__ text, const u16* __restrict__ map, u64 n, int b,
-                                                       SortGeom g, u32* __restrict__ hist) {
+                                                       SortGeom g, u32* __restrict__ hist, int low_k0 = 0) {
     constexpr int CS = RADIX + 1;
     constexpr u32 SPAN = 256 * 16;
     __shared__ u32 s_h[TOP_HIST_COPIES * CS];
@@ -414,11 +417,15 @@ __global__ __launch_bounds__(256) void top_hist_kernel(const u8* __restrict__ te
         if (c != cur) { flush(cur); cur = c; }
         const u64 p0 = base + (u64)threadIdx.x * 16;
         if (p0 < n) {
-            // 32 bytes from p0 (the buffer is readable TEXT_PAD >= 32 bytes past n)
-            const uint4 x0 = *reinterpret_cast<const uint4*>(text + p0);
-            const uint4 x1 = *reinterpret_cast<const uint4*>(text + p0 + 16);
+            // 32 bytes from p0 + off (the buffer is readable TEXT_PAD >= 32 + 64 bytes past n); off = 0 for the top digit
+            const u64 off = low_k0 ? (u64)(low_k0 - c8) : 0;
+            uint4 x0, x1;
+            __builtin_memcpy(&x0, text + p0 + off, 16);
+            __builtin_memcpy(&x1, text + p0 + off + 16, 16);
             const u32 w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-            const u32 live = (n - p0 < 32) ? (u32)(n - p0) : 32u;   // bytes of the text among the 32
+            const u64 first = p0 + off;
+            const u32 live = (first >= n) ? 0u : ((n - first < 32) ? (u32)(n - first) : 32u);   // bytes of the text among the 32
+            const u32 npos = (n - p0 < 16) ? (u32)(n - p0) : 16u;                                 // positions of this thread
             u32 win = 0;
 #pragma unroll
             for (int k = 0; k < 16 + c8 - 1; ++k) {
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(256) void top_hist_kernel(const u8* __restrict__ te
                 const u32 code = ((u32)k < live) ? (u32)s_map[byte] : 0u;
                 win = ((win << b) | code) & wmask;
                 const int i = k - (c8 - 1);   // the window now ends at k: it is the one of position p0 + i
-                if (i >= 0 && (u32)i < live) atomicAdd(&my[win >> dshift], 1u);
+                if (i >= 0 && (u32)i < npos) atomicAdd(&my[low_k0 ? (win & 255u) : (win >> dshift)], 1u);
             }
         }
     }
@@ -674,6 +681,234 @@ __global__ __launch_bounds__(BLOCK, (TEXT_ITEMS > 16) ? 4 : 6) void text_top_pas
         text_top_tile<false, BLOCK>(a, tile, chunk, (u32)rest, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
 }
 
+// ---- pass 0 of the plain LSD sort straight from the text ---------------------------------------------------
+// Keys of more than 40 bits (word / name / log-like text: 12 characters of 5 bits) are sorted as (u64 key, u32 suffix)
+// records by radix_sort_pairs.  Its pass 0 used to read a key array that keygen_kernel had written for that one read
+// (9 + 20 bytes per character); this kernel assembles the keys of a tile in registers from the text as
+// text_top_pass_kernel does and then IS pass 0: ranked by the LOWEST digit, values = positions, u64 keys + u32 values
+// out, the (chunk, next digit) histogram of pass 1 counted on the way: 1 + 12 bytes per character.
+struct TextLowArgs {
+    SortPassArgs p;         // keys_in / vals_in unused; keys_out u64, vals_out, geometry, digits, look-back state
+    const u8* text;
+    const u16* map;
+    u64 n;
+    int b, k0;              // key = k0 characters of b bits, MSB first, in bits [64 - b * k0, 64); b <= 8
+};
+
+template <bool FULL, int BLOCK>
+__device__ __forceinline__ void text_low_tile(const TextLowArgs& t, const u32 tile, const u32 chunk, const u32 tile_n,
+                                              u64* s_keys, u32* s_whist, uint2* s_tab, u32* s_wsum, const u8* s_map) {
+    constexpr int WAVES = BLOCK / WAVE;
+    constexpr int ITEMS = SORT_ITEMS;
+    constexpr u32 TILE = BLOCK * ITEMS;
+    const SortPassArgs& a = t.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 first_tile = chunk * a.g.tpc;
+    const u64 tile_base = (u64)tile * TILE;
+    const u32 woff = (u32)wave * (WAVE * ITEMS) + lane;
+    const u32 dbase = (tid < RADIX) ? a.digit_base[chunk * RADIX + tid] : 0u;
+
+    // 0. text -> codes, staged in the LDS region that holds the sorted keys later (every code is read before the first
+    //    key is written: two barriers lie between)
+    u8* s_code = reinterpret_cast<u8*>(s_keys);
+    auto stage16 = [&](u32 local, auto checked) {
+        constexpr bool CHECK = decltype(checked)::value;
+        const u64 p0 = tile_base + local;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (!CHECK || p0 < t.n) x = *reinterpret_cast<const uint4*>(t.text + p0);
+        const u32 w[4] = {x.x, x.y, x.z, x.w};
+        const u32 live = CHECK ? (u32)((t.n > p0) ? ((t.n - p0 < 16) ? (t.n - p0) : 16) : 0) : 16u;
+        u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const u32 byte = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
+            const u32 code = (!CHECK || (u32)k < live) ? (u32)s_map[byte] : 0u;
+            o[k >> 2] |= code << ((k & 3) * 8);
+        }
+        *reinterpret_cast<uint4*>(s_code + local) = make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    for (u32 local = (u32)tid * 16u; local < TILE; local += BLOCK * 16u) {
+        if (FULL) stage16(local, std::false_type{}); else stage16(local, std::true_type{});
+    }
+    if (tid < TEXT_HALO / 16) stage16(TILE + (u32)tid * 16u, std::true_type{});
+    __syncthreads();
+
+    // 1. keys of the lane's positions woff + 64 j, one character per step (see text_top_tile)
+    u32 hi[ITEMS], lo[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) { hi[j] = 0; lo[j] = 0; }
+    const u8* cp = s_code + woff;
+    {
+        int c = 0;
+        for (; c < t.k0 && 64 - t.b * (c + 1) >= 32; ++c, ++cp) {
+            const int s_hi = 32 - t.b * (c + 1);
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) shl_or_inplace(hi[j], (u32)cp[j * WAVE], s_hi);
+        }
+        if (c < t.k0 && 64 - t.b * c > 32) {
+            const int sh = 64 - t.b * (c + 1);   // 0 < sh < 32 < sh + b
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const u32 code = cp[j * WAVE];
+                hi[j] |= code >> (32 - sh);
+                lo[j] |= code << sh;
+            }
+            ++c; ++cp;
+        }
+        for (; c < t.k0; ++c, ++cp) {
+            const int sh = 64 - t.b * (c + 1);
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) shl_or_inplace(lo[j], (u32)cp[j * WAVE], sh);
+        }
+    }
+    u64 key[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) key[j] = ((u64)hi[j] << 32) | lo[j];
+
+    // 2. rank by the pass's digit
+    u32 rd[ITEMS];
+    u32* wh = s_whist + wave * RADIX;
+    wave_rank<FULL>(key, a.shift, a.mask, woff, tile_n, wh, rd);
+    __syncthreads();   // also: every read of the staged codes is done
+
+    // 3. tile digit counts -> aggregate -> exclusive scan over digits
+    u32 count = 0, excl = 0;
+    if (tid < RADIX) {
+        u32 c = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const u32 x = s_whist[w * RADIX + tid];
+            s_whist[w * RADIX + tid] = c;
+            c += x;
+        }
+        count = c;
+        __hip_atomic_store(&a.status[(u64)tile * RADIX + tid], pack_status(a.epoch, tile == first_tile ? FLAG_INCL : FLAG_AGG, count),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u32 incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 x = __shfl_up(incl, o);
+            if (lane >= o) incl += x;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        excl = incl - c;
+    }
+    __syncthreads();
+    if (tid < RADIX) {
+        for (int i = 0; i < wave; ++i) excl += s_wsum[i];
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) s_whist[w * RADIX + tid] += excl;
+    }
+    __syncthreads();
+
+    // 4. keys -> LDS at their tile-local sorted position
+    u32 pos[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        pos[j] = wh[rd[j] >> 16] + (rd[j] & 0xFFFFu);
+        if (FULL || (woff + j * WAVE) < tile_n) s_keys[pos[j]] = key[j];
+    }
+    __syncthreads();
+
+    // 5. look-back; the other lanes clear the (chunk, next digit) histogram that reuses s_whist
+    const bool has_next = a.next_shift >= 0;
+    if (has_next) for (int i = tid; i < NCHUNK * RADIX; i += BLOCK) s_whist[i] = 0;
+    if (tid < RADIX) {
+        u32 prefix = 0;
+        if (tile > first_tile) {
+            prefix = lookback_prefix(a.status, tile, first_tile, (u32)tid, a.epoch, a.dstat);
+            if (((tile - first_tile) & a.incl_mask) == a.incl_mask)
+                __hip_atomic_store(&a.status[(u64)tile * RADIX + tid], pack_status(a.epoch, FLAG_INCL, prefix + count),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const u32 g0 = dbase + prefix;
+        const u32 gdelta = g0 - excl;
+        const u32 c0 = chunk_of_tile(g0 >> a.g.tile_shift, a.g.tpc);
+        const u64 bnd = (u64)(c0 + 1) * a.g.tpc << a.g.tile_shift;
+        u32 thr = 0xFFFFu;
+        if (c0 + 1 < (u32)NCHUNK && bnd < (u64)g0 + count) thr = (u32)(bnd - gdelta);
+        s_tab[tid] = make_uint2(gdelta, (c0 << 16) | thr);
+    }
+    __syncthreads();
+
+    // 6. coalesced stores per digit run (+ pass 1's per-chunk histogram), then the positions
+    u32 gidx[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const u32 p = k * BLOCK + tid;
+        if (FULL || p < tile_n) {
+            const u64 kk = s_keys[p];
+            const uint2 tb = s_tab[digit_of(kk, a.shift, a.mask)];
+            gidx[k] = tb.x + p;
+            a.keys_out[gidx[k]] = kk;
+            if (has_next) {
+                const u32 dn = digit_of(kk, a.next_shift, a.next_mask);
+                const u32 cn = (tb.y >> 16) + (p >= (tb.y & 0xFFFFu) ? 1u : 0u);
+                atomicAdd(&s_whist[cn * RADIX + dn], 1u);
+            }
+        }
+    }
+    sync_lds();
+    if (has_next) {
+        for (int i = tid; i < NCHUNK * RADIX; i += BLOCK) {
+            const u32 v = s_whist[i];
+            if (v) atomicAdd(&a.next_hist[i], v);
+        }
+    }
+    u32* s_vals = reinterpret_cast<u32*>(s_keys);
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+        if (FULL || (woff + j * WAVE) < tile_n) s_vals[pos[j]] = (u32)tile_base + woff + j * WAVE;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const u32 p = k * BLOCK + tid;
+        if (FULL || p < tile_n) a.vals_out[gidx[k]] = s_vals[p];
+    }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 4) void text_low_pass_kernel(TextLowArgs t) {
+    constexpr int WAVES = BLOCK / WAVE;
+    constexpr u32 TILE = BLOCK * SORT_ITEMS;
+    constexpr int WH = (WAVES * RADIX > NCHUNK * RADIX) ? WAVES * RADIX : NCHUNK * RADIX;
+    static_assert(TILE * 8 >= TILE + TEXT_HALO, "the staged codes fit the key array's LDS");
+    __shared__ __attribute__((aligned(16))) u64 s_keys[TILE];
+    __shared__ u32 s_whist[WH];
+    __shared__ uint2 s_tab[RADIX];
+    __shared__ u32 s_wsum[RADIX / WAVE];
+    __shared__ u8 s_map[256];
+    __shared__ u32 s_tile;
+    __shared__ u32 s_chunk;
+    const SortPassArgs& a = t.p;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        u32 tile = 0xFFFFFFFFu, chunk = 0;
+        const u32 home = xcc_id();
+        for (int k = 0; k < NCHUNK; ++k) {
+            const u32 c = (home + k) & (NCHUNK - 1);
+            const u32 first = c * a.g.tpc;
+            if (first >= a.g.tiles) continue;
+            const u32 cnt = (a.g.tiles - first) < a.g.tpc ? (a.g.tiles - first) : a.g.tpc;
+            const u32 x = atomicAdd(&a.ticket[c], 1u);
+            if (x < cnt) { tile = first + x; chunk = c; break; }
+        }
+        s_tile = tile;
+        s_chunk = chunk;
+    }
+    if (tid < 256) s_map[tid] = (u8)t.map[tid];
+    for (int i = tid; i < WAVES * RADIX; i += BLOCK) s_whist[i] = 0;
+    __syncthreads();
+    const u32 tile = s_tile;
+    if (tile == 0xFFFFFFFFu) return;
+    const u32 chunk = s_chunk;
+    const u64 rest = t.n - (u64)tile * TILE;
+    if (rest >= (u64)TILE)
+        text_low_tile<true, BLOCK>(t, tile, chunk, TILE, s_keys, s_whist, s_tab, s_wsum, s_map);
+    else
+        text_low_tile<false, BLOCK>(t, tile, chunk, (u32)rest, s_keys, s_whist, s_tab, s_wsum, s_map);
+}
+
 // ---- host driver --------------------------------------------------------------------------------------
 struct NarrowWorkspace {
     SegPlan* plan = nullptr;
@@ -733,6 +968,37 @@ inline int narrow_text_histogram(RadixWorkspace& ws, NarrowWorkspace& nw, hipStr
         default: hipLaunchKernelGGL(top_hist_kernel<8>, grid, block, 0, stream, text, nw.map_dev, (u64)n, b, g, ws.hist(0)); break;
     }
     return 0;
+}
+
+// What a text-sourced pass 0 of the plain sort needs in place of key generation: the code map on the device and the
+// per-chunk histogram of the LOWEST digit of every position's key in ws.hist(0) (radix_prepare() before).
+inline int wide_text_histogram(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_t stream, const u8* text, const CodeMap& map,
+                               u32 n, int b, int k0) {
+    nw.map_host = map;
+    SA_HIP_CHECK(hipMemcpyAsync(nw.map_dev, nw.map_host.code, sizeof(CodeMap), hipMemcpyHostToDevice, stream));
+    const SortGeom g = make_geom(n, ws.tile());
+    const u32 spans = div_up(n, 4096);
+    const dim3 grid(spans < 2048u ? spans : 2048u), block(256);
+    switch ((8 + b - 1) / b) {
+        case 1: hipLaunchKernelGGL(top_hist_kernel<1>, grid, block, 0, stream, text, nw.map_dev, (u64)n, b, g, ws.hist(0), k0); break;
+        case 2: hipLaunchKernelGGL(top_hist_kernel<2>, grid, block, 0, stream, text, nw.map_dev, (u64)n, b, g, ws.hist(0), k0); break;
+        case 3: hipLaunchKernelGGL(top_hist_kernel<3>, grid, block, 0, stream, text, nw.map_dev, (u64)n, b, g, ws.hist(0), k0); break;
+        case 4: hipLaunchKernelGGL(top_hist_kernel<4>, grid, block, 0, stream, text, nw.map_dev, (u64)n, b, g, ws.hist(0), k0); break;
+        default: hipLaunchKernelGGL(top_hist_kernel<8>, grid, block, 0, stream, text, nw.map_dev, (u64)n, b, g, ws.hist(0), k0); break;
+    }
+    return 0;
+}
+struct WideTextCtx {
+    const u8* text;
+    const u16* map;
+    u64 n;
+    int b, k0;
+};
+inline void launch_text_low_pass(void* ctx, hipStream_t stream, const SortPassArgs& a, u32 grid) {
+    const WideTextCtx* c = static_cast<const WideTextCtx*>(ctx);
+    TextLowArgs t;
+    t.p = a; t.text = c->text; t.map = c->map; t.n = c->n; t.b = c->b; t.k0 = c->k0;
+    hipLaunchKernelGGL((text_low_pass_kernel<512>), dim3(grid), dim3(512), 0, stream, t);
 }
 
 // Sort n records (key[i], i) by key bits [begin_bit, 64), stable.

@@ -626,9 +626,16 @@ inline int radix_prepare(RadixWorkspace& ws, hipStream_t stream) {
 // on return *keys_res / *vals_res point at the buffers holding the result.  iota_vals: the
 // first pass generates value = position instead of reading valsA.  hist_ready: the caller ran
 // radix_prepare() and a producer kernel already filled ws.hist(0) for exactly this plan.
+// pass0 (may be null): launches pass 0 in place of radix_onesweep_kernel -- a producer that makes the keys on the fly
+// (radix_narrow.hpp: text_low_pass_kernel reads the text instead of a key array; keysA is then never touched).
+struct Pass0Launcher {
+    void (*launch)(void* ctx, hipStream_t stream, const SortPassArgs& a, u32 grid) = nullptr;
+    void* ctx = nullptr;
+    u32 bytes_per_record = 20;   // algorithmic bytes of that pass (read + written)
+};
 inline int radix_sort_pairs(RadixWorkspace& ws, hipStream_t stream, u64* keysA, u32* valsA, u64* keysB, u32* valsB,
                             u32 n, int begin_bit, int end_bit, bool iota_vals, bool hist_ready, u64** keys_res,
-                            u32** vals_res) {
+                            u32** vals_res, const Pass0Launcher* pass0 = nullptr) {
     *keys_res = keysA;
     *vals_res = valsA;
     if (n == 0 || end_bit <= begin_bit) {
@@ -675,11 +682,14 @@ inline int radix_sort_pairs(RadixWorkspace& ws, hipStream_t stream, u64* keysA, 
         a.narrow_shift = 0;
         if ((rc = ws.timer.start(stream, 0))) return rc;
         const u32 grid = pl.g.tiles;   // one tile per workgroup
-        if (ws.block == 512)
+        const bool by_producer = (p == 0 && pass0 && pass0->launch);
+        if (by_producer)
+            pass0->launch(pass0->ctx, stream, a, grid);
+        else if (ws.block == 512)
             hipLaunchKernelGGL((radix_onesweep_kernel<512, 0>), dim3(grid), dim3(512), 0, stream, a);
         else
             hipLaunchKernelGGL((radix_onesweep_kernel<256, 0>), dim3(grid), dim3(256), 0, stream, a);
-        const u64 pass_b = (u64)n * (a.vals_in ? 24u : 20u);   // pass 0 of a build generates its values
+        const u64 pass_b = (u64)n * (by_producer ? pass0->bytes_per_record : (a.vals_in ? 24u : 20u));   // pass 0 of a build generates its values
         if ((rc = ws.timer.stop(stream, pass_b))) return rc;
         ws.pass_records += n;
         ws.pass_bytes += pass_b;

@@ -949,6 +949,7 @@ struct Builder {
     bool fuse_hist = true;            // SA_HIP_FUSE_HIST: digit histograms inside keygen
     bool fuse_directory = true;       // SA_HIP_FUSE_DIR: query directory written by the first flags pass
     bool text_top_pass = true;        // SA_HIP_TEXT_PASS: the top-digit pass of a narrow sort builds its keys from the text
+    bool wide_text_pass = true;       // SA_HIP_WIDE_TEXT_PASS: pass 0 of the 12-byte-record sort builds its keys from the text
     bool narrow_sort = true;          // SA_HIP_NARROW: 8-byte records for initial keys of <= 40 bits (radix_narrow.hpp)
     DevBuf partial, dbg, done;
     bool tiny_finisher = true;        // SA_HIP_TINY: direct-comparison finisher for groups of <= 8
@@ -1036,6 +1037,7 @@ struct Builder {
         if (const char* e = getenv("SA_HIP_FUSE_DIR")) fuse_directory = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_NARROW")) narrow_sort = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_TEXT_PASS")) text_top_pass = atoi(e) != 0;
+        if (const char* e = getenv("SA_HIP_WIDE_TEXT_PASS")) wide_text_pass = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_NARROW_K")) narrow_k = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_TINY")) tiny_finisher = atoi(e) != 0;
         if (const char* e = getenv("SA_HIP_LOCAL_ROUNDS")) local_rounds = atoi(e) != 0;
@@ -1492,8 +1494,14 @@ struct Builder {
         stats.text_top_pass = text_pass ? 1u : 0u;
         // (a narrow sort fed from a u64 key array -- no text pass -- needs the wide buffers for that array)
         if ((rc = ensure_key_buffers(n, narrow_path && text_pass && narrow_k && fuse_directory))) return rc;
+        // the plain 12-byte-record sort can take its pass 0 from the text too (no key array written and read back)
+        const bool wide_text = !narrow_path && wide_text_pass && fuse_hist && radix.block == 512 && text_pass_applies(b, k0) &&
+                               pl.npasses > 1 && n >= (1u << 16);
+        stats.text_top_pass = (text_pass || wide_text) ? 1u : 0u;
         if (text_pass) {
             if ((rc = narrow_text_histogram(radix, narrow, stream, text.as<u8>(), map, n32, b))) return rc;
+        } else if (wide_text) {
+            if ((rc = wide_text_histogram(radix, narrow, stream, text.as<u8>(), map, n32, b, k0))) return rc;
         } else {
             hipLaunchKernelGGL(keygen_kernel, dim3(stream_grid(n, BLD_TILE)), dim3(BLD_BLOCK), 0, stream, text.as<u8>(), n, map, b,
                                k0, keys0.as<u64>(), pl.g, narrow_path ? 56 : pl.shift(0), narrow_path ? 255u : pl.mask(0),
@@ -1510,8 +1518,13 @@ struct Builder {
             if ((rc = radix_sort_narrow(radix, narrow, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(),
                                         n32, begin_bit, &kres, &vres, text_pass ? &src : nullptr, keep_narrow, sa64_out))) return rc;
             if (sa64_out) stats.widen_fused = 1;
-        } else if ((rc = radix_sort_pairs(radix, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(), n32,
-                                          begin_bit, 64, true, fuse_hist, &kres, &vres))) return rc;
+        } else {
+            WideTextCtx wctx{text.as<u8>(), narrow.map_dev, n, b, k0};
+            Pass0Launcher p0;
+            p0.launch = &launch_text_low_pass; p0.ctx = &wctx; p0.bytes_per_record = 13;
+            if ((rc = radix_sort_pairs(radix, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(), n32,
+                                       begin_bit, 64, true, fuse_hist, &kres, &vres, wide_text ? &p0 : nullptr))) return rc;
+        }
         sa = vres;
         // sorted packed keys: kept for the query path (sa_query.hpp)
         NarrowKeys nk{};

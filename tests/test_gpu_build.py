@@ -319,3 +319,46 @@ def test_build_device64_is_the_libsais64_layout(gpu, oracle, monkeypatch):
             assert np.array_equal(got[:t.size], exp.astype(np.int64)), name
         for k in env:
             monkeypatch.delenv(k, raising=False)
+
+
+def test_wide_sort_from_the_text_matches_key_array(gpu, oracle, monkeypatch):
+    """Keys of more than 40 bits are sorted as 12-byte records; pass 0 of that sort reads the text itself
+    (text_low_pass_kernel: keys assembled in registers, ranked by the LOWEST digit, next-pass histogram on the way)
+    instead of a key array written by keygen_kernel (SA_HIP_WIDE_TEXT_PASS=0): same suffix array bit for bit, verified,
+    equal to the oracle -- word text (12 five-bit characters), forced key lengths (9..12 characters: last passes of 5, 2,
+    7 and 4 bits), a four-letter alphabet (21 characters of 3 bits), 200 symbols (8-bit codes), truncated builds, texts
+    whose last tile is partial, and a 256-symbol text (9-bit codes: the text pass does not apply, both runs use keygen)."""
+    from suffixarray_amd import synth
+    rng = np.random.default_rng(123)
+    words = synth.d2_words(5_000_003)
+    dna = (rng.integers(0, 4, 3_000_000).astype(np.uint8) + 97)
+    sym200 = rng.choice(np.arange(20, 220, dtype=np.uint8), 2_500_000)
+    runs = [("words", words, 0, {}), ("words_L30", words, 30, {}), ("words_k9", words, 0, {"SA_HIP_INITIAL_CHARS": "9"}),
+            ("words_k10", words, 0, {"SA_HIP_INITIAL_CHARS": "10"}), ("words_k11", words, 0, {"SA_HIP_INITIAL_CHARS": "11"}),
+            ("d1_plain", synth.d1_uniform27(4_600_000), 0, {"SA_HIP_NARROW": "0"}), ("d1_plain_k12", synth.d1_uniform27(300_000), 0, {"SA_HIP_INITIAL_CHARS": "12"}),
+            ("dna", dna, 0, {}), ("sym200", sym200, 0, {"SA_HIP_INITIAL_CHARS": "7"}),
+            ("bytes256", rng.integers(0, 256, 2_000_000).astype(np.uint8), 0, {"SA_HIP_INITIAL_CHARS": "6"}),
+            ("d2_300k", cases.small_texts()["d2_300k"], 0, {}), ("r27_65537", cases.small_texts()["r27_65537"], 0, {"SA_HIP_INITIAL_CHARS": "12"})]
+    for name, t, L, env in runs:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got, st = {}, {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SA_HIP_WIDE_TEXT_PASS", mode)
+            with gpu.DeviceIndex(t.size, 0) as idx:
+                idx.build(t, L)
+                st[mode] = idx.build_stats()
+                assert idx.verify() == 0, (name, mode, st[mode])
+                got[mode] = idx.sa_u32().copy()
+                pats = cases.query_patterns(t, 500, rng)
+                assert np.array_equal(idx.query_batch(pats), oracle.query_batch(t, got[mode], L if L else 0xFFFFFFFF, pats)), (name, mode)
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        assert np.array_equal(got["1"], got["0"]), (name, st)
+        assert st["0"]["pass_launches"][0] > 0 and st["0"]["text_top_pass"] == 0, (name, st["0"])     # the 12-byte-record plan ran
+        if name != "bytes256":
+            assert st["1"]["text_top_pass"] == 1, (name, st["1"])
+            assert st["1"]["radix_bytes"] < st["0"]["radix_bytes"], name
+        exp = oracle.truncated_sa(t, L) if L else oracle.sais(t).astype(np.uint32)
+        assert np.array_equal(got["1"], exp), name
+    monkeypatch.delenv("SA_HIP_WIDE_TEXT_PASS", raising=False)
