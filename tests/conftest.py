@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:   # torch first: a process must end up with ONE HIP runtime -- the library that is loaded first decides which
+    import torch  # noqa: F401  (tests that hand torch device buffers to the C ABI run in this process)
+except Exception:   # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
