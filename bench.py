@@ -226,6 +226,7 @@ def main():
     ap.add_argument("--cpu-one-thread-chars", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--offsets-api", action="store_true", help="query through sa_hip_query_batch_device (offsets array) instead of the fixed-length entry")
     ap.add_argument("--separate-widen", action="store_true", help="int64 output by a widening pass after the build (A/B against the fused form)")
     ap.add_argument("--exercise-dist", action="store_true",
                     help="run the multi-GPU path (RCCL init, index broadcast, sharded batch, all-gather) at world size 1")
@@ -275,7 +276,11 @@ def run_single(args, torch, _capi, synth, dev, device):
             idx.widen_device(sa64_t.data_ptr())
         else:
             idx.build_device64(text_dev, N, sa64_t.data_ptr(), 0)
-        idx.query_batch_device(pat_t.data_ptr(), off_t.data_ptr(), Q, out_t.data_ptr())
+        # every pattern has m bytes: the fixed-length entry point (no offsets array to read); --offsets-api: the general one
+        if args.offsets_api:
+            idx.query_batch_device(pat_t.data_ptr(), off_t.data_ptr(), Q, out_t.data_ptr())
+        else:
+            idx.query_batch_device_fixed(pat_t.data_ptr(), m, Q, out_t.data_ptr())
         idx.sync()
 
     for _ in range(args.warmup):
@@ -328,7 +333,7 @@ def run_single(args, torch, _capi, synth, dev, device):
           "reference_model": {"bytes_per_query": bq, "achieved": q_model / 1e9,
                               "note": "bytes of the REFERENCE algorithm per query (SURVEY 8d: 2*ceil(log2 N)*(4+m)); the directory and the key "
                                       "array replace most of its probes, so this is not what the kernel moves"}}
-    if pmc_q and pmc_q.get("queries") == Q:
+    if pmc_q and pmc_q.get("queries") == Q and not args.offsets_api:
         # measured HBM bytes of one batch (rocprofv3 --pmc, profiles/pmc_query.json) over THIS run's kernel time
         tq = pmc_q["traffic_bytes_per_launch"]
         rq.update(traffic=tq, bytes_per_query=tq / Q, achieved=tq / (query_ms / steps / 1e3) / 1e9,
@@ -462,7 +467,10 @@ def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
     batch = ShardedBatch(q_buf, q_off, Qg, world, rank, dev)
 
     def search(pat_t, off_t, q_local, out_t):
-        searcher.query_batch_device(pat_t.data_ptr(), off_t.data_ptr(), q_local, out_t.data_ptr())
+        if args.offsets_api:
+            searcher.query_batch_device(pat_t.data_ptr(), off_t.data_ptr(), q_local, out_t.data_ptr())
+        else:
+            searcher.query_batch_device_fixed(pat_t.data_ptr(), m, q_local, out_t.data_ptr())
         searcher.sync()   # the index has its own stream; the gather runs on torch's
 
     for _ in range(args.warmup):

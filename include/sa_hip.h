@@ -149,6 +149,10 @@ int sa_hip_query_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_
  * partial 8-byte word is loaded whole and masked (the host-pointer form pads its staging copy itself). */
 int sa_hip_query_batch_device(sa_hip_index* idx, const void* patterns_dev, const void* offsets_dev,
                               uint64_t Q, void* out_dev);
+/* The same for Q patterns of ONE length, packed back to back (pattern i = patterns_dev[i * pattern_len ..)): no offsets
+ * array -- two 8-byte loads per query less (a batch is bound by the number of memory requests).  The
+ * padding rule of sa_hip_query_batch_device applies (8 readable bytes past the last pattern). */
+int sa_hip_query_batch_device_fixed(sa_hip_index* idx, const void* patterns_dev, uint64_t pattern_len, uint64_t Q, void* out_dev);
 /* Copy up to `cap` suffix positions SA[first .. first+count) to the host (hit materialisation). */
 int sa_hip_index_get_sa_range(sa_hip_index* idx, uint64_t first, uint64_t count, uint32_t* out_host);
 /* ONE query with its first hits, the latency path of record retrieval (get_matching_records, engine.c:1167-1215,

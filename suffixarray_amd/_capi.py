@@ -23,7 +23,7 @@ EXPORTS = [
     "sa_hip_index_build_device", "sa_hip_index_build_device64", "sa_hip_index_load", "sa_hip_index_load_device", "sa_hip_index_n",
     "sa_hip_index_max_suffix_length", "sa_hip_index_text_dev", "sa_hip_index_sa_dev",
     "sa_hip_index_stream", "sa_hip_index_get_sa_u32", "sa_hip_index_get_sa_i64", "sa_hip_index_widen_device",
-    "sa_hip_index_get_freq", "sa_hip_query_batch", "sa_hip_query_batch_device",
+    "sa_hip_index_get_freq", "sa_hip_query_batch", "sa_hip_query_batch_device", "sa_hip_query_batch_device_fixed",
     "sa_hip_index_get_sa_range", "sa_hip_index_query_hits", "sa_hip_index_sync", "sa_hip_index_verify", "sa_hip_index_build_stats",
     "sa_hip_index_set_rows", "sa_hip_index_query_rows", "sa_hip_index_rows_for_range", "sa_hip_csv_index_copy_rows", "sa_hip_index_get_text", "sa_hip_csv_index_create", "sa_hip_csv_index_adopt",
     "sa_hip_csv_index_destroy", "sa_hip_csv_index_handle", "sa_hip_csv_index_num_rows", "sa_hip_csv_index_num_columns",
@@ -140,6 +140,8 @@ def lib():
     L.sa_hip_query_batch.argtypes = [vp, vp, vp, u64, vp]
     L.sa_hip_query_batch_device.restype = C.c_int
     L.sa_hip_query_batch_device.argtypes = [vp, vp, vp, u64, vp]
+    L.sa_hip_query_batch_device_fixed.restype = C.c_int
+    L.sa_hip_query_batch_device_fixed.argtypes = [vp, vp, u64, u64, vp]
     L.sa_hip_index_get_sa_range.restype = C.c_int
     L.sa_hip_index_get_sa_range.argtypes = [vp, u64, u64, vp]
     L.sa_hip_index_query_hits.restype = C.c_int
@@ -379,6 +381,10 @@ class DeviceIndex:
 
     def query_batch_device(self, patterns_dev_ptr, offsets_dev_ptr, q, out_dev_ptr):
         check(self._lib.sa_hip_query_batch_device(self._h, patterns_dev_ptr, offsets_dev_ptr, q, out_dev_ptr))
+
+    def query_batch_device_fixed(self, patterns_dev_ptr, pattern_len, q, out_dev_ptr):
+        """q patterns of pattern_len bytes each, packed back to back in device memory (no offsets array)."""
+        check(self._lib.sa_hip_query_batch_device_fixed(self._h, patterns_dev_ptr, pattern_len, q, out_dev_ptr))
 
 
 # -- libsais- / engine-compatible one-shot wrappers ----------------------------------------------

@@ -52,8 +52,9 @@ int set_device(int device) {
     return 0;
 }
 
-int launch_query(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q, sa_hip_pair_u32* out_dev) {
+int launch_query(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q, sa_hip_pair_u32* out_dev, u64 fixed_len = 0) {
     QueryArgs a;
+    a.fixed_len = fixed_len;
     a.text = idx->b.text.as<u8>();
     a.sa = idx->b.sa;
     a.n = idx->b.n;
@@ -405,6 +406,17 @@ int sa_hip_query_batch_device(sa_hip_index* idx, const void* patterns_dev, const
     int rc = set_device(idx->device);
     if (rc) return rc;
     return launch_query(idx, (const u8*)patterns_dev, (const u64*)offsets_dev, Q, (sa_hip_pair_u32*)out_dev);
+}
+
+int sa_hip_query_batch_device_fixed(sa_hip_index* idx, const void* patterns_dev, uint64_t pattern_len, uint64_t Q, void* out_dev) {
+    if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_query_batch_device_fixed: NULL index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_query_batch_device_fixed: no index");
+    if (Q == 0) return 0;
+    if ((!patterns_dev && pattern_len) || !out_dev) return fail(SA_HIP_EINVAL, "sa_hip_query_batch_device_fixed: NULL argument");
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    return launch_query(idx, (const u8*)patterns_dev, nullptr, Q, (sa_hip_pair_u32*)out_dev, pattern_len);
 }
 
 int sa_hip_index_build_stats(const sa_hip_index* idx_c, sa_hip_build_stats* out) {

@@ -85,7 +85,8 @@ struct QueryArgs {
     u64 n;
     u32 max_suffix_length;  // 0 = unlimited
     const u8* patterns;     // packed; zero padded by >= 8 readable bytes
-    const u64* offsets;     // [q + 1]
+    const u64* offsets;     // [q + 1]; nullptr: every pattern has fixed_len bytes, pattern i at patterns + i * fixed_len
+    u64 fixed_len;
     u64 q;
     sa_hip_pair_u32* out;
     // acceleration structures (keys == nullptr: plain SA/text descent)
@@ -169,8 +170,8 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
     __syncthreads();
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 qi = (u64)blockIdx.x * blockDim.x + threadIdx.x; qi < a.q; qi += stride) {
-        const u64 o = a.offsets[qi];
-        const u64 len = a.offsets[qi + 1] - o;
+        const u64 o = a.offsets ? a.offsets[qi] : qi * a.fixed_len;   // (uniform branch)
+        const u64 len = a.offsets ? a.offsets[qi + 1] - o : a.fixed_len;
         u32 c = len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)len;
         if (a.max_suffix_length && c > a.max_suffix_length) c = a.max_suffix_length;
         const u8* q = a.patterns + o;

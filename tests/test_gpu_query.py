@@ -410,3 +410,35 @@ def test_sector_search_matches_binary_search(gpu, oracle, monkeypatch):
         for k, v in got.items():
             assert np.array_equal(v, exp), (name, k)
     monkeypatch.delenv("SA_HIP_SECTOR_SEARCH", raising=False)
+
+
+def test_fixed_length_batch_equals_offsets_batch(gpu, oracle):
+    """sa_hip_query_batch_device_fixed (Q patterns of one length, no offsets array -- what bench.py calls) against
+    sa_hip_query_batch_device and the oracle, for lengths around the word size of the pattern loads and beyond the key."""
+    import torch
+    from suffixarray_amd import synth
+    rng = np.random.default_rng(8)
+    for t, L in ((synth.d1_uniform27(4_600_000), 0), (synth.d2_words(3_000_000), 0), (synth.d2_words(3_000_000), 20)):
+        with gpu.DeviceIndex(t.size, 0) as idx:
+            idx.build(t, L)
+            sa = idx.sa_u32()
+            for m in (1, 2, 7, 8, 9, 16, 31, 32, 33, 40):
+                q = 3000
+                pos = rng.integers(0, t.size - m, q)
+                pats = np.stack([t[p:p + m] for p in pos])
+                pats[1::2] = rng.integers(97, 123, (q // 2, m), dtype=np.uint8)
+                flat = np.ascontiguousarray(pats.reshape(-1))
+                off = (np.arange(q + 1, dtype=np.uint64) * np.uint64(m))
+                exp = oracle.query_batch(t, sa, L if L else 0xFFFFFFFF, (flat, off))
+                d_pat = torch.from_numpy(np.concatenate([flat, np.zeros(64, np.uint8)])).to("cuda:0")
+                d_off = torch.from_numpy(off.view(np.int64)).to("cuda:0")
+                out_a = torch.zeros(2 * q, dtype=torch.int32, device="cuda:0")
+                out_b = torch.zeros(2 * q, dtype=torch.int32, device="cuda:0")
+                torch.cuda.synchronize()
+                idx.query_batch_device_fixed(d_pat.data_ptr(), m, q, out_a.data_ptr())
+                idx.query_batch_device(d_pat.data_ptr(), d_off.data_ptr(), q, out_b.data_ptr())
+                idx.sync()
+                a = out_a.cpu().numpy().view(np.uint32).reshape(-1, 2)
+                b = out_b.cpu().numpy().view(np.uint32).reshape(-1, 2)
+                assert np.array_equal(a, b), (m, L)
+                assert np.array_equal(a[:, 0], exp["first"]) and np.array_equal(a[:, 1], exp["second"]), (m, L)
