@@ -1,9 +1,13 @@
 // sa_build.hpp -- device suffix-array construction for gfx950: alphabet compaction, packed
-// initial keys, one-sweep radix sort, then refinement over the ACTIVE set only (suffixes whose
-// group is not yet a singleton): a direct-comparison finisher for tiny groups when the active set
-// is sparse, "chunk" rounds that append the next characters of the text to the key, "doubling"
-// rounds (Larsson-Sadakane with discarding) that append the rank of suffix i+h.
-// tests/pipeline_model.py is the executable specification of the host logic.
+// initial keys, one-sweep radix sort (narrow 8-byte records for keys of <= 40 bits, 12-byte records
+// otherwise; the first pass of either reads the text itself), then refinement over the ACTIVE set
+// only (suffixes whose group is not yet a singleton): a direct-comparison finisher for tiny groups
+// when the active set is sparse, the in-LDS group finisher (group_finish.hpp: every group that fits a
+// tile is refined to the end by one workgroup), and for what is left "chunk" rounds that append the
+// next characters of the text to the key and "doubling" rounds (Larsson-Sadakane with discarding)
+// that append the rank of suffix i+h.  A 64-bit build also leaves the result as int64 (libsais64
+// layout): stored by the sort's last pass, patched where refinement wrote later.
+// tests/pipeline_model.py is the executable specification of the host logic of the rounds.
 //
 // Replaces, by function only, libsais / libsais64 (libsais.c:6618, libsais64.c:6657: T -> SA)
 // and construct_truncated_suffix_array (engine.c:837-866).  Order: unsigned bytes, a suffix
@@ -12,7 +16,7 @@
 //
 // HBM layout (n = text bytes, M = active records of a round):
 //   text     u8 [n + TEXT_PAD]   zero padded, read coalesced (keygen) or by random 8..64 B windows
-//   keys0/1  u64[n]              ping-pong sort keys (initial sort)
+//   keys0/1  u64[n] or u32[n]     ping-pong sort keys (initial sort; sized once the plan is known)
 //   vals0/1  u32[n]              ping-pong suffix indices; the result buffer IS the suffix array
 //   flags    u8 [n]              bit0 = group head at this SA slot
 //   isa      u32[n]              rank of every suffix (allocated on the first doubling round)
