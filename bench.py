@@ -228,6 +228,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--offsets-api", action="store_true", help="query through sa_hip_query_batch_device (offsets array) instead of the fixed-length entry")
     ap.add_argument("--separate-widen", action="store_true", help="int64 output by a widening pass after the build (A/B against the fused form)")
+    ap.add_argument("--dist-chunks", type=int, default=4, help="pieces a rank's slice is searched and gathered in (pipelined)")
+    ap.add_argument("--dist-mode", choices=("all_gather", "gather_to_root"), default="all_gather")
+    ap.add_argument("--dump", default=None, help="config 4: write the gathered ranges (+ the SA for N <= 1e8) to this .npz (tests)")
     ap.add_argument("--exercise-dist", action="store_true",
                     help="run the multi-GPU path (RCCL init, index broadcast, sharded batch, all-gather) at world size 1")
     args = ap.parse_args()
@@ -376,8 +379,13 @@ def run_single(args, torch, _capi, synth, dev, device):
                                              "doubling_rounds", "final_depth", "radix_passes", "active_total", "narrow_k")},
         "roofline": {"bound": "hbm", "kernel": PASS_KERNELS[dom], "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                     # PMC passes cannot run inside this process: `traffic` is REPLAYED from the committed counter run of the same
+                     # kernel on the same workload (profiles/pmc_onesweep.json), not measured in this run
                      "traffic": pmc_sort["traffic_bytes_per_launch"] if pmc_sort else None,
-                     "traffic_note": "bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE on this workload, profiles/pmc_onesweep.json",
+                     "traffic_source": "committed_pmc" if pmc_sort else None,
+                     "traffic_committed_pmc": pmc_sort["traffic_bytes_per_launch"] if pmc_sort else None,
+                     "traffic_note": "bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE on this workload, REPLAYED from the committed run "
+                                     "profiles/pmc_onesweep.json (keyed on kernel name and N), not collected in this process",
                      "launches": kind_launches[dom], "avg_launch_ms": pass_ms, "bytes_per_launch": bytes_per_launch},
         "sort_passes": {"achieved": all_achieved / 1e9, "unit": "GB/s", "frac": all_achieved / HBM_PEAK, "launches": radix_launches,
                         "by_kernel": {PASS_KERNELS[k]: {"launches": kind_launches[k], "avg_launch_ms": kind_ms[k] / kind_launches[k],
@@ -418,7 +426,7 @@ def run_single(args, torch, _capi, synth, dev, device):
 
 def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
     """BASELINE config 4 (see the module docstring)."""
-    from suffixarray_amd.distributed import ShardedBatch, broadcast_index, device_view, shard_bounds
+    from suffixarray_amd.distributed import ShardedBatch, replicate_index, shard_bounds
     N, Qg, m = args.n, args.queries_global, args.pattern_len
     text = synth.d1_uniform27(N)                     # the same text on every rank: rank 0 indexes it, all draw patterns from it
 
@@ -436,58 +444,52 @@ def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
             idx.build_device(idx.text_dev, N, 0)
             bms.append(idx.build_stats()["total_ms"])
         build_ms = min(bms[1:]) if len(bms) > 1 else bms[0]
-        tx_t = device_view(idx.text_dev, N, torch.uint8, dev)       # the index's own buffers: no staging copy
-        sa_t = device_view(idx.sa_dev, N, torch.int32, dev)
-    else:
-        tx_t = torch.empty(N, dtype=torch.uint8, device=dev)
-        sa_t = torch.empty(N, dtype=torch.int32, device=dev)
-    # replication: one RCCL broadcast per tensor
+    # replication: the builder's query structures (text, SA, key array, directory) by one RCCL broadcast per buffer
+    # straight into buffers the replica has reserved; nothing is rebuilt there (sa_hip_index_replica_*).
+    # (--exercise-dist: rank 0 too answers from a replica of its own index -- a device-to-device copy stands in for the
+    # broadcast -- so that a single GPU runs every line a receiving rank runs.)
+    searcher = idx
+    dst = None
+    if rank == 0 and args.exercise_dist:
+        searcher = dst = _capi.DeviceIndex(N, local_rank)
+    elif rank != 0:
+        dst = idx
     barrier()
     b0 = time.perf_counter()
-    broadcast_index(tx_t, sa_t, src=0)
+    bcast_bytes = replicate_index(idx if rank == 0 else None, dst, dev, src=0)
+    searcher.sync()
     barrier()
     bcast_ms = (time.perf_counter() - b0) * 1e3
-    searcher = idx
-    if rank != 0 or args.exercise_dist:
-        # adopts the replica: key array + directory, no construction.  (--exercise-dist: rank 0 too answers from an adopted
-        # copy of its own index, so that a single GPU runs every line a non-building rank runs.)
-        if rank == 0:
-            searcher = _capi.DeviceIndex(N, local_rank)
-        t0 = time.perf_counter()
-        searcher.load_device(tx_t.data_ptr(), sa_t.data_ptr(), N, 0)
-        searcher.sync()
-        adopt_ms = (time.perf_counter() - t0) * 1e3
-    else:
-        adopt_ms = 0.0
-    del tx_t, sa_t
 
     # ONE global batch, the same on every rank; this rank's slice goes to its GPU
     lo, hi = shard_bounds(Qg, world, rank)
     q_buf, q_off = synth.query_batch(text, Qg, m, seed=0, lo=lo, hi=hi)
-    batch = ShardedBatch(q_buf, q_off, Qg, world, rank, dev)
+    batch = ShardedBatch(q_buf, q_off, Qg, world, rank, dev, chunks=args.dist_chunks, mode=args.dist_mode,
+                         search_stream=torch.cuda.ExternalStream(searcher.stream, device=dev))
 
-    def search(pat_t, off_t, q_local, out_t):
+    def search(pat_t, off_t, start, count, out_t):
+        # asynchronous on the index's own stream; ShardedBatch orders it against the collectives with events
         if args.offsets_api:
-            searcher.query_batch_device(pat_t.data_ptr(), off_t.data_ptr(), q_local, out_t.data_ptr())
+            searcher.query_batch_device(pat_t.data_ptr(), off_t.data_ptr() + 8 * start, count, out_t.data_ptr())
         else:
-            searcher.query_batch_device_fixed(pat_t.data_ptr(), m, q_local, out_t.data_ptr())
-        searcher.sync()   # the index has its own stream; the gather runs on torch's
+            searcher.query_batch_device_fixed(pat_t.data_ptr() + m * start, m, count, out_t.data_ptr())
 
     for _ in range(args.warmup):
         batch.step(search)
     barrier()
+    searcher.query_stats()   # drops the warm-up launches from the sums
     kern_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         batch.step(search)
-        kern_ms += searcher.query_stats()["kernel_ms"]
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt, kern_ms, adopt_ms], dtype=torch.float64, device=dev)
+    kern_ms = searcher.query_stats()["kernel_ms_sum"]
+    tmax = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt, kern_ms_max, adopt_ms_max = tmax.tolist()
+    dt, kern_ms_max = tmax.tolist()
 
-    # gate: the gathered table (every rank holds it) equals what rank 0's own index answers for the whole batch
+    # gate: the gathered table equals what rank 0's own (built) index answers for the whole batch
     gate = None
     got = batch.results()
     if rank == 0:
@@ -497,6 +499,8 @@ def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
         hits = (((got["second"].astype(np.int64) - got["first"].astype(np.int64) + 1) & 0xFFFFFFFF) > 0) & (got["first"] != 0xFFFFFFFF)
         gate = {"gathered_equals_single_gpu": same, "verify_violations": idx.verify(), "query_hit_rate": float(hits.mean())}
         gate["ok"] = bool(same and gate["verify_violations"] == 0)
+        if args.dump:   # tests/test_gpu_dist.py: the gathered ranges and the suffix array, to be checked against the oracle
+            np.savez(args.dump, first=got["first"], second=got["second"], sa=idx.sa_u32() if N <= 100_000_000 else np.zeros(0, np.uint32))
     steps = args.steps
     line = None
     if rank == 0:
@@ -514,17 +518,19 @@ def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
             "dtype": "u8 text / u32 suffix indices / u32 range pairs",
             "data": "synthetic",
             "config": {"workload": f"config 4: D1 uniform27 text N={N:,}, ONE batch of {Qg:,} {m}-byte queries sharded over {world} GPU(s), "
-                                   "SA built on rank 0 and replicated by RCCL broadcast, ranges all-gathered",
+                                   f"index built on rank 0 and replicated by RCCL broadcast, ranges gathered ({args.dist_mode}, {batch.chunks} chunks per step)",
                        "n_chars": N, "queries_global": Qg, "pattern_len": m,
-                       "parallelism": f"replicated index, query batch sharded x{world} (no data-path collective; all_gather_into_tensor of 8-byte ranges)"},
+                       "parallelism": f"replicated index, query batch sharded x{world} (no data-path collective; {args.dist_mode} of 8-byte ranges, "
+                                      f"search of chunk k+1 overlapped with the gather of chunk k)"},
             "search_kernel_ms_max_rank": kern_ms_max / steps,
             "search_only_queries_per_s": Qg * steps / (kern_ms_max / 1e3) if kern_ms_max > 0 else None,
             "build_ms": build_ms,
             "build_chars_per_s": N / (build_ms / 1e3),
-            "broadcast_ms": bcast_ms,
-            "broadcast_bytes": 5 * N,
-            "broadcast_gbps": 5 * N / (bcast_ms / 1e3) / 1e9,
-            "adopt_ms_max_rank": adopt_ms_max,
+            "replicate_ms": bcast_ms,
+            "replicate_bytes": bcast_bytes,
+            "replicate_gbps": bcast_bytes / (bcast_ms / 1e3) / 1e9,
+            "replicate_note": "layout + text + SA + key array + directory into reserved buffers, SA range check; nothing is rebuilt on the replica "
+                              "(sa_hip_index_replica_*); at world size 1 a device-to-device copy stands in for the broadcast",
             "gate": gate,
         }
     if searcher is not idx:

@@ -116,6 +116,35 @@ int sa_hip_index_load(sa_hip_index* idx, const uint8_t* T_host, const uint32_t* 
 int sa_hip_index_load_device(sa_hip_index* idx, const void* T_dev, const void* SA_dev, uint64_t n,
                              uint32_t max_suffix_length);
 
+/* Replicas without any rebuilding (no counterpart in the reference).  The query structures of a built
+ * index -- text, suffix array, sorted key array, bucket directory -- are plain device buffers; a replica reserves
+ * buffers of the same layout, the caller fills them (RCCL broadcast straight into them: sa_hip_comm_broadcast_index,
+ * or torch.distributed over the same pointers), and commit makes the replica searchable after range-checking the
+ * suffix array and the directory's ends on the device.  Nothing is gathered, sorted or searched on the replica. */
+typedef struct sa_hip_replica_layout {
+    uint64_t n;
+    uint32_t max_suffix_length;
+    uint32_t key_bytes;          /* 0: no key array (n < 2); 4: u32 narrow keys; 8: u64 keys                */
+    uint32_t bits_per_symbol;    /* of the packed keys                                                      */
+    uint32_t initial_chars;
+    uint32_t dir_bits;
+    int32_t  lo_shift;           /* narrow keys: key = (bucket << 56) | (narrow << lo_shift)                */
+    uint64_t dir_entries;        /* 2^dir_bits + 1                                                          */
+    uint16_t code[256];          /* alphabet compaction of the text                                         */
+    uint64_t freq[256];
+} sa_hip_replica_layout;
+typedef struct sa_hip_replica_buffers {
+    void* text; void* sa; void* keys; void* dir;          /* device pointers on the index's device        */
+    uint64_t text_bytes, sa_bytes, keys_bytes, dir_bytes;  /* what has to travel                            */
+} sa_hip_replica_buffers;
+/* Layout and buffers of a built (or loaded) index: the source of a replication. */
+int sa_hip_index_replica_layout(sa_hip_index* idx, sa_hip_replica_layout* out);
+int sa_hip_index_replica_buffers(sa_hip_index* idx, sa_hip_replica_buffers* out);
+/* Destination: allocate buffers for `layout` (n <= the handle's capacity) and return where to receive.  The index has
+ * no searchable state until sa_hip_index_replica_commit. */
+int sa_hip_index_replica_reserve(sa_hip_index* idx, const sa_hip_replica_layout* layout, sa_hip_replica_buffers* out);
+int sa_hip_index_replica_commit(sa_hip_index* idx);
+
 uint64_t sa_hip_index_n(const sa_hip_index* idx);
 uint32_t sa_hip_index_max_suffix_length(const sa_hip_index* idx);
 /* Device pointers owned by the index: text (n bytes + zero padding) and SA (uint32[n]). */
@@ -173,8 +202,8 @@ int sa_hip_index_verify(sa_hip_index* idx, uint64_t* violations);
 /* ---- (5) record retrieval: hits -> rows (engine.c:920-999, 1168-1215, 1326-1390; bound at pyx:87-101) -------------- */
 
 /* Row table of the indexed text: row r (a document, or one CSV field) = text[row_text_starts[r], row_text_starts[r+1]);
- * row_text_starts[0] must be 0 and the offsets ascend.  The table is copied.  Not to be called while queries run on
- * the same handle. */
+ * row_text_starts[0] must be 0 and the offsets ascend.  The table is copied (under the handle's lock, like every
+ * reader of it). */
 int sa_hip_index_set_rows(sa_hip_index* idx, const uint64_t* row_text_starts, uint64_t num_rows);
 /* ONE query -> the distinct rows that contain the pattern, in SA order of their first hit, at most k of them
  * (row_ids[0 .. *num_rows)); *range (may be NULL) as in sa_hip_query_batch.  The reference returns one record per HIT
@@ -286,10 +315,15 @@ typedef struct sa_hip_build_stats {
 } sa_hip_build_stats;
 int sa_hip_index_build_stats(const sa_hip_index* idx, sa_hip_build_stats* out);
 
-/* Per-query-batch statistics of the last batch on this handle. */
+/* Statistics of the search launches on this handle.  kernel_ms: the last launch; kernel_ms_sum / launches: every launch
+ * since the previous call of sa_hip_index_query_stats (a pipelined step issues several; the library keeps HIP events
+ * for the last 32 launches and resolves them here -- the call waits for them). */
 typedef struct sa_hip_query_stats {
-    uint64_t q;
-    double   kernel_ms;          /* HIP-event time of the search kernel(s)                 */
+    uint64_t q;                  /* patterns of the last launch                            */
+    double   kernel_ms;          /* HIP-event time of the last search kernel               */
+    double   kernel_ms_sum;      /* ... of all launches since the previous call            */
+    uint32_t launches;
+    uint32_t pad_;
 } sa_hip_query_stats;
 int sa_hip_index_query_stats(const sa_hip_index* idx, sa_hip_query_stats* out);
 

@@ -30,6 +30,7 @@ EXPORTS = [
     "sa_hip_csv_index_column_index", "sa_hip_csv_index_column_name", "sa_hip_csv_index_row_tables",
     "sa_hip_get_substring_positions_file", "sa_hip_get_matching_records_file", "sa_hip_get_matching_records", "sa_hip_free_records",
     "sa_hip_init_suffix_array_byte_idxs", "sa_hip_free_suffix_array",
+    "sa_hip_index_replica_layout", "sa_hip_index_replica_buffers", "sa_hip_index_replica_reserve", "sa_hip_index_replica_commit",
     "sa_hip_index_query_stats", "sa_hip_csv_extract_column", "sa_hip_csv_free", "sa_hip_synth_csv", "sa_hip_sort_pairs", "sa_hip_synth_uniform27", "sa_hip_last_error", "sa_hip_version",
 ]
 
@@ -68,7 +69,24 @@ class CsvColumn(C.Structure):
 
 
 class QueryStats(C.Structure):
-    _fields_ = [("q", C.c_uint64), ("kernel_ms", C.c_double)]
+    _fields_ = [("q", C.c_uint64), ("kernel_ms", C.c_double), ("kernel_ms_sum", C.c_double), ("launches", C.c_uint32),
+                ("pad_", C.c_uint32)]
+
+
+class ReplicaLayout(C.Structure):
+    """sa_hip_replica_layout: what a replica must know about the index it copies (travels as bytes)."""
+    _fields_ = [("n", C.c_uint64), ("max_suffix_length", C.c_uint32), ("key_bytes", C.c_uint32), ("bits_per_symbol", C.c_uint32),
+                ("initial_chars", C.c_uint32), ("dir_bits", C.c_uint32), ("lo_shift", C.c_int32), ("dir_entries", C.c_uint64),
+                ("code", C.c_uint16 * 256), ("freq", C.c_uint64 * 256)]
+
+
+class ReplicaBuffers(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("sa", C.c_void_p), ("keys", C.c_void_p), ("dir", C.c_void_p),
+                ("text_bytes", C.c_uint64), ("sa_bytes", C.c_uint64), ("keys_bytes", C.c_uint64), ("dir_bytes", C.c_uint64)]
+
+    def items(self):
+        """(device pointer, bytes) of every buffer that has to travel, in a fixed order"""
+        return [(getattr(self, k) or 0, int(getattr(self, k + "_bytes"))) for k in ("text", "sa", "keys", "dir")]
 
 
 class SaHipError(RuntimeError):
@@ -118,6 +136,14 @@ def lib():
     L.sa_hip_index_load.argtypes = [vp, vp, vp, u64, u32]
     L.sa_hip_index_load_device.restype = C.c_int
     L.sa_hip_index_load_device.argtypes = [vp, vp, vp, u64, u32]
+    L.sa_hip_index_replica_layout.restype = C.c_int
+    L.sa_hip_index_replica_layout.argtypes = [vp, C.POINTER(ReplicaLayout)]
+    L.sa_hip_index_replica_buffers.restype = C.c_int
+    L.sa_hip_index_replica_buffers.argtypes = [vp, C.POINTER(ReplicaBuffers)]
+    L.sa_hip_index_replica_reserve.restype = C.c_int
+    L.sa_hip_index_replica_reserve.argtypes = [vp, C.POINTER(ReplicaLayout), C.POINTER(ReplicaBuffers)]
+    L.sa_hip_index_replica_commit.restype = C.c_int
+    L.sa_hip_index_replica_commit.argtypes = [vp]
     L.sa_hip_index_n.restype = u64
     L.sa_hip_index_n.argtypes = [vp]
     L.sa_hip_index_max_suffix_length.restype = u32
@@ -297,6 +323,32 @@ class DeviceIndex:
         check(self._lib.sa_hip_index_load_device(self._h, text_dev_ptr, sa_dev_ptr, n, max_suffix_length))
         return self
 
+    # -- replicas: the query structures travel as they are (no rebuilding on the receiving side) ------------
+    def replica_layout(self):
+        lay = ReplicaLayout()
+        check(self._lib.sa_hip_index_replica_layout(self._h, C.byref(lay)))
+        return lay
+
+    def replica_buffers(self):
+        """Device buffers of this (built) index: the source of a replication."""
+        b = ReplicaBuffers()
+        check(self._lib.sa_hip_index_replica_buffers(self._h, C.byref(b)))
+        return b
+
+    def replica_reserve(self, layout):
+        """Allocate buffers for `layout`; returns where the caller has to put the data (then replica_commit)."""
+        b = ReplicaBuffers()
+        check(self._lib.sa_hip_index_replica_reserve(self._h, C.byref(layout), C.byref(b)))
+        return b
+
+    def replica_commit(self):
+        check(self._lib.sa_hip_index_replica_commit(self._h))
+
+    @property
+    def stream(self):
+        """The index's hipStream_t as an integer (torch.cuda.ExternalStream wraps it for event ordering)."""
+        return self._lib.sa_hip_index_stream(self._h)
+
     # -- accessors ----------------------------------------------------------------------------
     @property
     def n(self):
@@ -364,7 +416,7 @@ class DeviceIndex:
     def query_stats(self):
         st = QueryStats()
         check(self._lib.sa_hip_index_query_stats(self._h, C.byref(st)))
-        return {"q": st.q, "kernel_ms": st.kernel_ms}
+        return {"q": st.q, "kernel_ms": st.kernel_ms, "kernel_ms_sum": st.kernel_ms_sum, "launches": st.launches}
 
     # -- query ----------------------------------------------------------------------------------
     def query_batch(self, patterns):

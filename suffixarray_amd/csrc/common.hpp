@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -62,6 +63,14 @@ __device__ __forceinline__ u64 lanemask_lt() {
 __device__ __forceinline__ void sync_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
+}
+
+// Diagnostic switches (SA_HIP_*): read from the environment ONLY when SA_HIP_DIAG=1 is set as well -- the behaviour of a
+// production process does not depend on stray variables of its caller; the tests and tools/ set SA_HIP_DIAG=1 to run
+// both plans of a build on the same input.
+inline const char* diag_env(const char* name) {
+    static const bool on = [] { const char* d = getenv("SA_HIP_DIAG"); return d && atoi(d) != 0; }();
+    return on ? getenv(name) : nullptr;
 }
 
 // Alphabet compaction of a text: code = 1 + rank of the byte among the bytes that occur; 0 = past the end.

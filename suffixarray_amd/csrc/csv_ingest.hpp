@@ -250,7 +250,7 @@ inline void csv_parallel(u64 parts, F&& fn) {
 inline int csv_extract_column(const char* path, const char* column, sa_hip_csv_column* out) {
     memset(out, 0, sizeof *out);
     // SA_HIP_CSV_TIMING=1: phase times on stderr
-    const bool timing = getenv("SA_HIP_CSV_TIMING") && atoi(getenv("SA_HIP_CSV_TIMING")) != 0;
+    const bool timing = diag_env("SA_HIP_CSV_TIMING") && atoi(diag_env("SA_HIP_CSV_TIMING")) != 0;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!timing) return;

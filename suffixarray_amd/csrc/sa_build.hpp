@@ -1033,25 +1033,25 @@ struct Builder {
         if ((rc = text.ensure(cap + TEXT_PAD + 16))) return rc;
         if ((rc = small.ensure(4096))) return rc;
         int sort_block = 512;
-        if (const char* e = getenv("SA_HIP_SORT_BLOCK")) sort_block = (atoi(e) == 256) ? 256 : 512;
-        if (const char* e = getenv("SA_HIP_INITIAL_CHARS")) initial_chars_override = atoi(e);
-        if (const char* e = getenv("SA_HIP_CHUNK_ROUNDS")) chunk_rounds_before_doubling = atoi(e);
-        if (const char* e = getenv("SA_HIP_ADAPTIVE_DOUBLING")) adaptive_doubling = atoi(e) != 0;
-        if (const char* e = getenv("SA_HIP_FUSE_HIST")) fuse_hist = atoi(e) != 0;
-        if (const char* e = getenv("SA_HIP_FUSE_DIR")) fuse_directory = atoi(e) != 0;
-        if (const char* e = getenv("SA_HIP_NARROW")) narrow_sort = atoi(e) != 0;
-        if (const char* e = getenv("SA_HIP_TEXT_PASS")) text_top_pass = atoi(e) != 0;
-        if (const char* e = getenv("SA_HIP_WIDE_TEXT_PASS")) wide_text_pass = atoi(e) != 0;
-        if (const char* e = getenv("SA_HIP_NARROW_K")) narrow_k = atoi(e) != 0;
-        if (const char* e = getenv("SA_HIP_TINY")) tiny_finisher = atoi(e) != 0;
-        if (const char* e = getenv("SA_HIP_LOCAL_ROUNDS")) local_rounds = atoi(e) != 0;
-        if (const char* e = getenv("SA_HIP_GROUP_FINISH")) group_finish = atoi(e) != 0;
-        if (const char* e = getenv("SA_HIP_PILOT")) use_pilot = atoi(e) != 0;
-        if (const char* e = getenv("SA_HIP_SECTOR_SEARCH")) sector_search = atoi(e) != 0;
-        if (const char* e = getenv("SA_HIP_FIN_COUNT_MAX")) fin_count_max = (u32)atoi(e);
-        if (const char* e = getenv("SA_HIP_BIG_ROUND_CHARS")) big_round_chars = atoi(e);
-        if (const char* e = getenv("SA_HIP_FIN_RADIX_CHARS")) fin_radix_chars = atoi(e);
-        if (const char* e = getenv("SA_HIP_DEBUG_ROUNDS")) debug_rounds = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_SORT_BLOCK")) sort_block = (atoi(e) == 256) ? 256 : 512;
+        if (const char* e = diag_env("SA_HIP_INITIAL_CHARS")) initial_chars_override = atoi(e);
+        if (const char* e = diag_env("SA_HIP_CHUNK_ROUNDS")) chunk_rounds_before_doubling = atoi(e);
+        if (const char* e = diag_env("SA_HIP_ADAPTIVE_DOUBLING")) adaptive_doubling = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_FUSE_HIST")) fuse_hist = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_FUSE_DIR")) fuse_directory = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_NARROW")) narrow_sort = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_TEXT_PASS")) text_top_pass = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_WIDE_TEXT_PASS")) wide_text_pass = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_NARROW_K")) narrow_k = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_TINY")) tiny_finisher = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_LOCAL_ROUNDS")) local_rounds = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_GROUP_FINISH")) group_finish = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_PILOT")) use_pilot = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_SECTOR_SEARCH")) sector_search = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_FIN_COUNT_MAX")) fin_count_max = (u32)atoi(e);
+        if (const char* e = diag_env("SA_HIP_BIG_ROUND_CHARS")) big_round_chars = atoi(e);
+        if (const char* e = diag_env("SA_HIP_FIN_RADIX_CHARS")) fin_radix_chars = atoi(e);
+        if (const char* e = diag_env("SA_HIP_DEBUG_ROUNDS")) debug_rounds = atoi(e) != 0;
         if (debug_rounds) { radix.debug_hook = &Builder::sort_debug_hook; radix.debug_ctx = this; }
         if ((rc = radix.init(cap, sort_block))) return rc;
         if ((rc = narrow.init())) return rc;
@@ -1255,7 +1255,7 @@ struct Builder {
         int d = lg - 4;
         if (d < 8) d = 8;
         if (d > 27) d = 27;
-        if (const char* e = getenv("SA_HIP_DIR_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 28) d = v; }
+        if (const char* e = diag_env("SA_HIP_DIR_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 28) d = v; }
         q_dbits = d;
         const u64 nb = (1ull << d) + 1;
         return qdir.ensure(dir_gap_offset(nb) + (size_t)dir_gap_cap(nb) * sizeof(uint4));

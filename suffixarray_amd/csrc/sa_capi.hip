@@ -26,11 +26,20 @@ struct sa_hip_index {
     DevBuf widen;
     u8* qh_host = nullptr;   // pinned, device-mapped block of sa_hip_index_query_hits (QH_BYTES)
     u8* qh_dev = nullptr;    // the same block as the device sees it
-    hipEvent_t q_begin = nullptr, q_end = nullptr;
+    // HIP events of the last QRING search launches: a pipelined caller (distributed.py: search chunk k+1 while chunk k is
+    // gathered) asks for the statistics once per step, and every launch since the previous call is resolved then
+    static constexpr int QRING = 32;
+    hipEvent_t q_ev[QRING][2] = {};
+    int q_head = 0, q_pending = 0;
+    double q_sum_ms = 0.0;       // resolved launches since the last sa_hip_index_query_stats
+    double q_last_ms = 0.0;
+    u32 q_launches = 0;
     hipEvent_t w_begin = nullptr, w_end = nullptr;   // sa_hip_index_widen_device
     double widen_ms = 0.0;                           // < 0: recorded, not yet resolved
     sa_hip_query_stats qstats{};
     std::vector<u64> row_starts;   // sa_hip_index_set_rows: offset of every row (document, CSV field) in the indexed text
+    bool receiving = false;        // sa_hip_index_replica_reserve .. _commit: the buffers are being filled by the caller
+    sa_hip_replica_layout pending{};
 };
 
 // CSV-mode index (SuffixArrayIndex of the reference, engine.h:163-172): the device index over one column + the row
@@ -52,7 +61,23 @@ int set_device(int device) {
     return 0;
 }
 
+// resolves the `count` oldest pending launches of the event ring (blocks until they have finished)
+int resolve_query_events(sa_hip_index* idx, int count) {
+    for (; count > 0 && idx->q_pending > 0; --count) {
+        const int slot = (idx->q_head - idx->q_pending + 2 * sa_hip_index::QRING) % sa_hip_index::QRING;
+        SA_HIP_CHECK(hipEventSynchronize(idx->q_ev[slot][1]));
+        float ms = 0.f;
+        SA_HIP_CHECK(hipEventElapsedTime(&ms, idx->q_ev[slot][0], idx->q_ev[slot][1]));
+        idx->q_sum_ms += ms;
+        idx->q_last_ms = ms;
+        --idx->q_pending;
+    }
+    return 0;
+}
+
 int launch_query(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q, sa_hip_pair_u32* out_dev, u64 fixed_len = 0) {
+    if (idx->q_pending == sa_hip_index::QRING) { int rc = resolve_query_events(idx, 1); if (rc) return rc; }
+    hipEvent_t* ev = idx->q_ev[idx->q_head];
     QueryArgs a;
     a.fixed_len = fixed_len;
     a.text = idx->b.text.as<u8>();
@@ -69,17 +94,19 @@ int launch_query(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q
     a.sector_search = idx->b.sector_search ? 1 : 0;
     a.dir = idx->b.qdir.as<u32>();
     a.b = idx->b.q_b; a.k0 = idx->b.q_k0; a.dbits = idx->b.q_dbits;
-    SA_HIP_CHECK(hipEventRecord(idx->q_begin, idx->stream));
+    SA_HIP_CHECK(hipEventRecord(ev[0], idx->stream));
     if (Q) {
         u64 g = (Q + 255) / 256;
         if (g > 256u * 16u) g = 256u * 16u;
         if (a.keys32) hipLaunchKernelGGL(query_kernel<true>, dim3((u32)g), dim3(256), 0, idx->stream, a, idx->b.qmap);
         else hipLaunchKernelGGL(query_kernel<false>, dim3((u32)g), dim3(256), 0, idx->stream, a, idx->b.qmap);
     }
-    SA_HIP_CHECK(hipEventRecord(idx->q_end, idx->stream));
+    SA_HIP_CHECK(hipEventRecord(ev[1], idx->stream));
     SA_HIP_CHECK(hipGetLastError());
-    idx->qstats.q = Q;
-    idx->qstats.kernel_ms = -1.0;  // resolved lazily by sa_hip_index_query_stats
+    idx->q_head = (idx->q_head + 1) % sa_hip_index::QRING;
+    ++idx->q_pending;
+    ++idx->q_launches;
+    idx->qstats.q = Q;   // the times are resolved lazily by sa_hip_index_query_stats
     return 0;
 }
 
@@ -135,9 +162,10 @@ int sa_hip_index_create(sa_hip_index** out, uint64_t n_max, int device) {
     if (e != hipSuccess) { delete idx; return fail(SA_HIP_EHIP, "hipStreamCreate", hipGetErrorString(e)); }
     rc = idx->b.init(n_max, idx->stream);
     if (!rc) {
-        if (hipEventCreate(&idx->q_begin) != hipSuccess || hipEventCreate(&idx->q_end) != hipSuccess ||
-            hipEventCreate(&idx->w_begin) != hipSuccess || hipEventCreate(&idx->w_end) != hipSuccess)
-            rc = fail(SA_HIP_EHIP, "hipEventCreate");
+        bool ok = hipEventCreate(&idx->w_begin) == hipSuccess && hipEventCreate(&idx->w_end) == hipSuccess;
+        for (int i = 0; ok && i < sa_hip_index::QRING; ++i)
+            ok = hipEventCreate(&idx->q_ev[i][0]) == hipSuccess && hipEventCreate(&idx->q_ev[i][1]) == hipSuccess;
+        if (!ok) rc = fail(SA_HIP_EHIP, "hipEventCreate");
     }
     if (rc) { sa_hip_index_destroy(idx); return rc; }
     *out = idx;
@@ -151,8 +179,8 @@ void sa_hip_index_destroy(sa_hip_index* idx) {
     idx->b.destroy();
     idx->q_pat.release(); idx->q_off.release(); idx->q_out.release(); idx->widen.release();
     if (idx->qh_host) (void)hipHostFree(idx->qh_host);
-    if (idx->q_begin) (void)hipEventDestroy(idx->q_begin);
-    if (idx->q_end) (void)hipEventDestroy(idx->q_end);
+    for (int i = 0; i < sa_hip_index::QRING; ++i)
+        for (int k = 0; k < 2; ++k) if (idx->q_ev[i][k]) (void)hipEventDestroy(idx->q_ev[i][k]);
     if (idx->w_begin) (void)hipEventDestroy(idx->w_begin);
     if (idx->w_end) (void)hipEventDestroy(idx->w_end);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -246,6 +274,127 @@ int sa_hip_index_load_device(sa_hip_index* idx, const void* T_dev, const void* S
     return load_common(idx, T_dev, SA_dev, n, max_suffix_length, hipMemcpyDeviceToDevice);
 }
 
+// ---- replicas: the query structures travel as they are -----------------------------------------------
+// A replica used to receive text + SA and rebuild the key array by a random gather over the text and the directory by
+// binary search (sa_hip_index_load_device: 115 ms at n = 1e9, 5x a build).  The building index already holds all of it:
+// the replica reserves buffers of the same layout, the caller fills them (RCCL broadcast straight into them), commit
+// range-checks the suffix array.
+
+static void fill_layout(const sa_hip_index* idx, sa_hip_replica_layout* out) {
+    const Builder& b = idx->b;
+    memset(out, 0, sizeof *out);
+    out->n = b.n;
+    out->max_suffix_length = b.max_suffix_length;
+    out->key_bytes = b.qkeys32 ? 4u : (b.qkeys ? 8u : 0u);
+    out->bits_per_symbol = (uint32_t)b.q_b;
+    out->initial_chars = (uint32_t)b.q_k0;
+    out->dir_bits = out->key_bytes ? (uint32_t)b.q_dbits : 0u;
+    out->lo_shift = b.q_lo_shift;
+    out->dir_entries = out->key_bytes ? (1ull << b.q_dbits) + 1 : 0;
+    memcpy(out->code, b.qmap.code, sizeof out->code);
+    memcpy(out->freq, b.freq, sizeof out->freq);
+}
+
+int sa_hip_index_replica_layout(sa_hip_index* idx, sa_hip_replica_layout* out) {
+    if (!idx || !out) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_layout: NULL argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_layout: no index");
+    fill_layout(idx, out);
+    return 0;
+}
+
+static void fill_buffers(const sa_hip_index* idx, const sa_hip_replica_layout& l, sa_hip_replica_buffers* out) {
+    const Builder& b = idx->b;
+    memset(out, 0, sizeof *out);
+    out->text = b.text.p;                       out->text_bytes = l.n;
+    out->sa = b.sa;                             out->sa_bytes = l.n * 4;
+    out->keys = l.key_bytes == 4 ? (void*)b.qkeys32 : (void*)b.qkeys;
+    out->keys_bytes = l.n * l.key_bytes;
+    out->dir = l.key_bytes ? b.qdir.p : nullptr; out->dir_bytes = l.dir_entries * 4;
+}
+
+int sa_hip_index_replica_buffers(sa_hip_index* idx, sa_hip_replica_buffers* out) {
+    if (!idx || !out) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_buffers: NULL argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_buffers: no index");
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    SA_HIP_CHECK(hipStreamSynchronize(idx->stream));   // whoever reads the buffers next runs on another stream
+    sa_hip_replica_layout l;
+    fill_layout(idx, &l);
+    fill_buffers(idx, l, out);
+    return 0;
+}
+
+int sa_hip_index_replica_reserve(sa_hip_index* idx, const sa_hip_replica_layout* l, sa_hip_replica_buffers* out) {
+    if (!idx || !l || !out) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_reserve: NULL argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (l->n > idx->b.n_max) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_reserve: n exceeds the index capacity");
+    if (l->key_bytes != 0 && l->key_bytes != 4 && l->key_bytes != 8) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_reserve: bad key width");
+    if (l->key_bytes && (l->dir_bits < 8 || l->dir_bits > 28 || l->dir_entries != (1ull << l->dir_bits) + 1 || l->bits_per_symbol < 1 ||
+                         l->bits_per_symbol > 16 || l->initial_chars < 1 || l->initial_chars * l->bits_per_symbol > 64 ||
+                         l->lo_shift < 0 || l->lo_shift > 63))
+        return fail(SA_HIP_EINVAL, "sa_hip_index_replica_reserve: inconsistent layout");
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    Builder& b = idx->b;
+    idx->has_index = false;
+    if ((rc = b.sa_own.ensure((size_t)(l->n ? l->n : 1) * 4))) return rc;
+    if (l->key_bytes) {
+        if ((rc = b.keys0.ensure((size_t)l->n * l->key_bytes + 64))) return rc;
+        if ((rc = b.qdir.ensure((size_t)l->dir_entries * 4))) return rc;
+    }
+    SA_HIP_CHECK(hipMemsetAsync(b.text.as<u8>() + l->n, 0, TEXT_PAD + 16, idx->stream));
+    SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+    b.n = l->n;
+    b.sa = b.sa_own.as<u32>();
+    b.qkeys = nullptr; b.qkeys32 = nullptr; b.dir_ready = false;
+    idx->pending = *l;
+    idx->receiving = true;
+    memset(out, 0, sizeof *out);
+    out->text = b.text.p;     out->text_bytes = l->n;
+    out->sa = b.sa_own.p;     out->sa_bytes = l->n * 4;
+    out->keys = l->key_bytes ? b.keys0.p : nullptr; out->keys_bytes = l->n * l->key_bytes;
+    out->dir = l->key_bytes ? b.qdir.p : nullptr;   out->dir_bytes = l->dir_entries * 4;
+    return 0;
+}
+
+int sa_hip_index_replica_commit(sa_hip_index* idx) {
+    if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_commit: NULL index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx->receiving) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_commit: nothing reserved");
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    Builder& b = idx->b;
+    const sa_hip_replica_layout& l = idx->pending;
+    idx->receiving = false;
+    // what arrived is checked as far as it can send the search out of bounds: SA entries < n, the directory's ends
+    u64 bad_host = 0;
+    u32 dir_ends[2] = {0, (u32)l.n};
+    if (l.n) {
+        u64* bad = reinterpret_cast<u64*>(b.small.as<u8>() + 3072);
+        SA_HIP_CHECK(hipMemsetAsync(bad, 0, 8, idx->stream));
+        hipLaunchKernelGGL(sa_range_check_kernel, dim3(stream_grid(l.n, 1024)), dim3(256), 0, idx->stream, (const u32*)b.sa_own.p, l.n, bad);
+        SA_HIP_CHECK(hipMemcpyAsync(&bad_host, bad, 8, hipMemcpyDeviceToHost, idx->stream));
+        if (l.key_bytes) {
+            SA_HIP_CHECK(hipMemcpyAsync(&dir_ends[0], b.qdir.as<u32>(), 4, hipMemcpyDeviceToHost, idx->stream));
+            SA_HIP_CHECK(hipMemcpyAsync(&dir_ends[1], b.qdir.as<u32>() + (l.dir_entries - 1), 4, hipMemcpyDeviceToHost, idx->stream));
+        }
+        SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+    }
+    if (bad_host) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_commit: suffix array holds entries >= n");
+    if (dir_ends[0] != 0 || dir_ends[1] != (u32)l.n) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_commit: directory does not span the suffix array");
+    b.max_suffix_length = l.max_suffix_length;
+    memcpy(b.freq, l.freq, sizeof b.freq);
+    memcpy(b.qmap.code, l.code, sizeof l.code);
+    b.q_b = (int)l.bits_per_symbol; b.q_k0 = (int)l.initial_chars; b.q_dbits = (int)l.dir_bits; b.q_lo_shift = l.lo_shift;
+    b.qkeys = l.key_bytes == 8 ? b.keys0.as<u64>() : nullptr;
+    b.qkeys32 = l.key_bytes == 4 ? b.keys0.as<u32>() : nullptr;
+    b.dir_ready = l.key_bytes != 0;
+    idx->has_index = true;
+    return 0;
+}
+
 uint64_t sa_hip_index_n(const sa_hip_index* idx) { return idx ? idx->b.n : 0; }
 uint32_t sa_hip_index_max_suffix_length(const sa_hip_index* idx) { return idx ? idx->b.max_suffix_length : 0; }
 const void* sa_hip_index_text_dev(const sa_hip_index* idx) { return idx ? idx->b.text.p : nullptr; }
@@ -321,9 +470,8 @@ int sa_hip_index_widen_device(sa_hip_index* idx, void* out_dev) {
     return 0;
 }
 
-int sa_hip_index_get_sa_range(sa_hip_index* idx, uint64_t first, uint64_t count, uint32_t* out_host) {
-    if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: NULL index");
-    std::lock_guard<std::mutex> g(idx->mu);
+// (idx->mu held)
+static int get_sa_range_locked(sa_hip_index* idx, uint64_t first, uint64_t count, uint32_t* out_host) {
     if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: no index");
     if (first > idx->b.n || count > idx->b.n - first) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: out of range");
     if (!out_host && count) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: NULL output");
@@ -332,6 +480,12 @@ int sa_hip_index_get_sa_range(sa_hip_index* idx, uint64_t first, uint64_t count,
     if (count) SA_HIP_CHECK(hipMemcpyAsync(out_host, idx->b.sa + first, (size_t)count * 4, hipMemcpyDeviceToHost, idx->stream));
     SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
     return 0;
+}
+
+int sa_hip_index_get_sa_range(sa_hip_index* idx, uint64_t first, uint64_t count, uint32_t* out_host) {
+    if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: NULL index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    return get_sa_range_locked(idx, first, count, out_host);
 }
 
 int sa_hip_index_get_freq(sa_hip_index* idx, uint64_t* freq256) {
@@ -363,13 +517,12 @@ int sa_hip_query_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_
     return 0;
 }
 
-int sa_hip_index_query_hits(sa_hip_index* idx, const uint8_t* pattern, uint64_t len, uint32_t max_hits,
-                            sa_hip_pair_u32* range, uint32_t* hits, uint32_t* nhits) {
-    if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_query_hits: NULL index");
+// (idx->mu held)
+static int query_hits_locked(sa_hip_index* idx, const uint8_t* pattern, uint64_t len, uint32_t max_hits,
+                             sa_hip_pair_u32* range, uint32_t* hits, uint32_t* nhits) {
     if (!range || !nhits || (!pattern && len) || (!hits && max_hits)) return fail(SA_HIP_EINVAL, "sa_hip_index_query_hits: NULL argument");
     if (len > QH_BYTES - 64 - QH_OFF_PATTERN) return fail(SA_HIP_EINVAL, "sa_hip_index_query_hits: pattern longer than 47 KB");
     if (max_hits > QH_MAX_HITS) max_hits = QH_MAX_HITS;
-    std::lock_guard<std::mutex> g(idx->mu);
     if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_query_hits: no index");
     int rc = set_device(idx->device);
     if (rc) return rc;
@@ -394,6 +547,13 @@ int sa_hip_index_query_hits(sa_hip_index* idx, const uint8_t* pattern, uint64_t 
     memcpy(nhits, h + 8, 4);
     if (*nhits) memcpy(hits, h + QH_OFF_HITS, (size_t)*nhits * 4);
     return 0;
+}
+
+int sa_hip_index_query_hits(sa_hip_index* idx, const uint8_t* pattern, uint64_t len, uint32_t max_hits,
+                            sa_hip_pair_u32* range, uint32_t* hits, uint32_t* nhits) {
+    if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_query_hits: NULL index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    return query_hits_locked(idx, pattern, len, max_hits, range, hits, nhits);
 }
 
 int sa_hip_query_batch_device(sa_hip_index* idx, const void* patterns_dev, const void* offsets_dev, uint64_t Q,
@@ -442,13 +602,13 @@ int sa_hip_index_query_stats(const sa_hip_index* idx_c, sa_hip_query_stats* out)
     std::lock_guard<std::mutex> g(idx->mu);
     int rc = set_device(idx->device);
     if (rc) return rc;
-    if (idx->qstats.kernel_ms < 0.0) {
-        SA_HIP_CHECK(hipEventSynchronize(idx->q_end));
-        float ms = 0.f;
-        SA_HIP_CHECK(hipEventElapsedTime(&ms, idx->q_begin, idx->q_end));
-        idx->qstats.kernel_ms = ms;
-    }
+    if ((rc = resolve_query_events(idx, sa_hip_index::QRING))) return rc;
+    idx->qstats.kernel_ms = idx->q_last_ms;
+    idx->qstats.kernel_ms_sum = idx->q_sum_ms;
+    idx->qstats.launches = idx->q_launches;
     *out = idx->qstats;
+    idx->q_sum_ms = 0.0;
+    idx->q_launches = 0;
     return 0;
 }
 
@@ -483,17 +643,20 @@ int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t 
     *num_rows = 0;
     sa_hip_pair_u32 rg;
     u32 nh = 0;
+    std::lock_guard<std::mutex> g(idx->mu);   // the search, the slabs of hits and the row table under ONE acquisition
+    // more rows than the table holds cannot come back: k = 10^9 ("all") must not size anything
+    if ((u64)k > idx->row_starts.size()) k = (u32)idx->row_starts.size();
     const u32 cap = k ? std::min<u32>(std::max<u32>(4u * k, 1024u), QH_MAX_HITS) : 0u;
     try {
         std::vector<u32> first(cap ? cap : 1);
-        int rc = sa_hip_index_query_hits(idx, pattern, len, cap, &rg, first.data(), &nh);
+        int rc = query_hits_locked(idx, pattern, len, cap, &rg, first.data(), &nh);
         if (rc) return rc;
         if (range) *range = rg;
-        const std::vector<u64>& starts = idx->row_starts;   // (set_rows must not run concurrently with queries on the handle)
-        if (starts.empty() && k) return fail(SA_HIP_EINVAL, "sa_hip_index_query_rows: no row table (sa_hip_index_set_rows)");
+        const std::vector<u64>& starts = idx->row_starts;
+        if (starts.empty()) return k ? fail(SA_HIP_EINVAL, "sa_hip_index_query_rows: no row table (sa_hip_index_set_rows)") : 0;
         std::vector<u64> rows;
         rc = distinct_rows(starts, rg, k, first.data(), nh,
-                           [&](u64 pos, u64 count, u32* out) { return sa_hip_index_get_sa_range(idx, pos, count, out); }, rows);
+                           [&](u64 pos, u64 count, u32* out) { return get_sa_range_locked(idx, pos, count, out); }, rows);
         if (rc) return rc;
         for (size_t i = 0; i < rows.size(); ++i) row_ids[i] = rows[i];
         *num_rows = (uint32_t)rows.size();
@@ -504,14 +667,17 @@ int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t 
 int sa_hip_index_rows_for_range(sa_hip_index* idx, sa_hip_pair_u32 range, uint32_t k, uint64_t* row_ids, uint32_t* num_rows) {
     if (!idx || !num_rows || (!row_ids && k)) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: NULL argument");
     *num_rows = 0;
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: no index");
     if (range.first != 0xFFFFFFFFu && (u32)(range.second - range.first + 1u) != 0u &&
         ((u64)range.second >= idx->b.n || range.first > range.second)) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: range outside the suffix array");
+    if ((u64)k > idx->row_starts.size()) k = (u32)idx->row_starts.size();
     try {
         const std::vector<u64>& starts = idx->row_starts;
-        if (starts.empty() && k) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: no row table (sa_hip_index_set_rows)");
+        if (starts.empty()) return k ? fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: no row table (sa_hip_index_set_rows)") : 0;
         std::vector<u64> rows;
         int rc = distinct_rows(starts, range, k, nullptr, 0,
-                               [&](u64 pos, u64 count, u32* out) { return sa_hip_index_get_sa_range(idx, pos, count, out); }, rows);
+                               [&](u64 pos, u64 count, u32* out) { return get_sa_range_locked(idx, pos, count, out); }, rows);
         if (rc) return rc;
         for (size_t i = 0; i < rows.size(); ++i) row_ids[i] = rows[i];
         *num_rows = (uint32_t)rows.size();
@@ -590,6 +756,14 @@ int sa_hip_csv_index_adopt(sa_hip_csv_index** out, const char* csv_file, const u
         for (u32 i = 0; i < num_columns; ++i) { c->columns.emplace_back(p); p += c->columns.back().size() + 1; }
         if (num_rows) c->row_file_offsets.assign(row_file_offsets, row_file_offsets + num_rows + 1);
     } catch (const std::bad_alloc&) { delete c; return fail(SA_HIP_ENOMEM, "sa_hip_csv_index_adopt: out of host memory"); }
+    // the tables come from a file: a row is copied out of the mapping by [row_file_offsets[r], row_file_offsets[r + 1]) and found
+    // by row_text_starts -- both must ascend and stay inside what they index (csv_index_finish checks the last offset
+    // against the file's size)
+    for (u64 r = 0; r < num_rows; ++r) {
+        if (row_file_offsets[r] > row_file_offsets[r + 1]) { delete c; return fail(SA_HIP_EINVAL, "sa_hip_csv_index_adopt: row_file_offsets must ascend"); }
+        if (row_text_starts[r] > n) { delete c; return fail(SA_HIP_EINVAL, "sa_hip_csv_index_adopt: row_text_starts beyond the text"); }
+    }
+    if (column_index >= num_columns && num_columns) { delete c; return fail(SA_HIP_EINVAL, "sa_hip_csv_index_adopt: column_index out of range"); }
     int rc = sa_hip_index_create(&c->idx, n ? n : 1, device);
     if (!rc) rc = sa_hip_index_load(c->idx, text, SA, n, max_suffix_length);
     if (!rc) rc = sa_hip_index_set_rows(c->idx, row_text_starts, num_rows);
@@ -638,7 +812,9 @@ int sa_hip_get_matching_records_file(sa_hip_csv_index* c, const char* substring,
                                      uint32_t* num_matches) {
     if (!c || !c->idx || !substring || !num_matches || (!matching_records && k)) return fail(SA_HIP_EINVAL, "sa_hip_get_matching_records_file: NULL argument");
     if (*num_matches >= k) return 0;   // engine.c:1356: at most k - *num_matches more
-    const u32 want = k - *num_matches;
+    // never more than the file has rows: k = 10^9 ("all") must not size a 8 GB table
+    const u32 want = (u32)std::min<u64>(k - *num_matches, sa_hip_csv_index_num_rows(c));
+    if (want == 0) return 0;
     try {
         std::vector<u64> rows((size_t)want);
         u32 n = 0;
@@ -789,7 +965,7 @@ int sa_hip_sort_pairs(uint64_t* keys, uint32_t* values, uint64_t n, int begin_bi
     RadixWorkspace ws;
     DevBuf k0, k1, v0, v1;
     int sort_block = 512;
-    if (const char* e = getenv("SA_HIP_SORT_BLOCK")) sort_block = (atoi(e) == 256) ? 256 : 512;
+    if (const char* e = diag_env("SA_HIP_SORT_BLOCK")) sort_block = (atoi(e) == 256) ? 256 : 512;
     rc = ws.init(n, sort_block);
     if (!rc) rc = k0.ensure(n * 8);
     if (!rc) rc = k1.ensure(n * 8);

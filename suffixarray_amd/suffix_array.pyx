@@ -66,7 +66,7 @@ cdef extern from "sa_hip.h":
 
 
 cdef bytes _LOWER = bytes((c + 32) if 65 <= c <= 90 else c for c in range(256))
-FORMAT_VERSION = 2
+FORMAT_VERSION = 3
 
 
 cdef inline bytes ascii_lower(bytes b):
@@ -269,7 +269,9 @@ cdef class SuffixArray:
             raise RuntimeError("index not built")
         cdef bytes pat = ascii_lower(substring.encode("utf-8") if isinstance(substring, str) else bytes(substring))
         cdef const char* pp = pat
-        cdef uint32_t kk = <uint32_t>min(int(k), 0x7FFFFFFF)
+        # never more rows than the index has: k = 10**9 ("all") must not size any buffer
+        cdef uint64_t nrows = sa_hip_csv_index_num_rows(self._csv) if self._mode == "csv" else len(self._row_starts)
+        cdef uint32_t kk = <uint32_t>min(int(k), max(nrows, 1), 0x7FFFFFFF)
         cdef uint32_t n = 0
         cdef uint64_t plen = len(pat)
         cdef int rc
@@ -291,9 +293,8 @@ cdef class SuffixArray:
                     free(recs[i])
                 free(recs)
             return _split_rows(self.columns, raw)
-        rows = np.empty(kk if kk < 4096 else min(kk, <uint32_t>max(len(self._row_starts), 1)), dtype=np.uint64)
+        rows = np.empty(kk, dtype=np.uint64)
         rv = rows
-        kk = <uint32_t>rows.shape[0]
         with nogil:
             rc = sa_hip_index_query_rows(self._idx, <const uint8_t*>pp, plen, kk, &rv[0], &n, NULL)
         _check(rc)
@@ -362,6 +363,10 @@ cdef class SuffixArray:
             np.asarray(<uint64_t[:rows + 1]>rfo).tofile(_os.path.join(directory, "row_file_offsets.u64"))
             meta["csv_filename"] = _os.path.abspath(self.csv_filename)
             meta["column_index"] = int(sa_hip_csv_index_column_index(self._csv))
+            # the identity of the file the row offsets point into: load() refuses a file that has changed
+            st = _os.stat(self.csv_filename)
+            meta["csv_size"] = int(st.st_size)
+            meta["csv_mtime_ns"] = int(st.st_mtime_ns)
         with open(_os.path.join(directory, "meta.json"), "w") as f:
             _json.dump(meta, f)
 
@@ -378,16 +383,26 @@ cdef class SuffixArray:
         if text.size != meta["n"] or sa.size != meta["n"]:
             raise ValueError("index files are truncated")
         starts = np.fromfile(_os.path.join(directory, "row_starts.u64"), dtype=np.uint64)
+        if starts.size and (starts[0] != 0 or starts[-1] > meta["n"] or np.any(starts[1:] < starts[:-1])):
+            raise ValueError("index files are corrupt (row table)")
         self.columns = meta["columns"]
         if meta["mode"] == "documents":
             with open(_os.path.join(directory, "documents.json")) as f:
                 self._documents = _json.load(f)
+            if len(self._documents) != starts.size:
+                raise ValueError("index files are truncated")
             self._build_documents(text.tobytes(), starts, sa if sa.size else np.zeros(1, np.uint32))
             self._mode = "documents"
             return self
         offs = np.fromfile(_os.path.join(directory, "row_file_offsets.u64"), dtype=np.uint64)
         if offs.size != starts.size + 1:
             raise ValueError("index files are truncated")
+        try:
+            st = _os.stat(meta["csv_filename"])
+        except OSError:
+            raise ValueError("the CSV file of this index is gone: " + meta["csv_filename"])
+        if int(st.st_size) != meta.get("csv_size") or int(st.st_mtime_ns) != meta.get("csv_mtime_ns"):
+            raise ValueError("the CSV file has changed since the index was saved (size / modification time): rebuild the index")
         cdef bytes fn = _os.fsencode(meta["csv_filename"])
         cdef bytes names = b"".join(c.encode("utf-8") + b"\0" for c in meta["columns"])
         cdef const char* fnp = fn

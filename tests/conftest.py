@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("SA_HIP_DIAG", "1")   # the SA_HIP_* plan switches the tests flip are only read with this set (csrc/common.hpp: diag_env)
+
 try:   # torch first: a process must end up with ONE HIP runtime -- the library that is loaded first decides which
     import torch  # noqa: F401  (tests that hand torch device buffers to the C ABI run in this process)
 except Exception:   # pragma: no cover

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, tmp):
+def _worker(rank, world, port, q, tmp, chunks=1, mode="all_gather"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -48,29 +48,33 @@ def _worker(rank, world, port, q, tmp):
     # ONE global batch; this rank generates and holds only its slice
     lo, hi = shard_bounds(q, world, rank)
     buf, off = synth.query_batch(ref_text, q, m, lo=lo, hi=hi)
-    batch = ShardedBatch(buf, off, q, world, rank, dev)
+    batch = ShardedBatch(buf, off, q, world, rank, dev, chunks=chunks, mode=mode)
 
-    def search(pat_t, off_t, q_local, out_t):
-        # the local searcher of the CPU test is the oracle; on the GPU it is sa_hip_query_batch_device
+    def search(pat_t, off_t, start, count, out_t):
+        # the local searcher of the CPU test is the oracle; on the GPU it is sa_hip_query_batch_device[_fixed]
         pat = pat_t.numpy()
-        offs = off_t.numpy().view(np.uint64)
-        res = o.query_batch(text, sa, 0xFFFFFFFF, (pat[:int(offs[-1])], offs), threads=1)
-        out_t[:2 * q_local] = torch.from_numpy(res.view(np.uint32).view(np.int32).copy())
+        offs = off_t.numpy().view(np.uint64)[start:start + count + 1]
+        res = o.query_batch(text, sa, 0xFFFFFFFF, (pat[int(offs[0]):int(offs[-1])], offs - offs[0]), threads=1)
+        out_t[:2 * count] = torch.from_numpy(res.view(np.uint32).view(np.int32).copy())
 
     for _ in range(2):   # the buffers are reused from step to step
         batch.step(search)
     got = batch.results()
-    fb, fo = synth.query_batch(ref_text, q, m)
-    exp = o.query_batch(ref_text, o.sais(ref_text).astype(np.uint32), 0xFFFFFFFF, (fb, fo), threads=1)
-    ok = np.array_equal(got["first"], exp["first"]) and np.array_equal(got["second"], exp["second"])
+    if got is None:      # gather_to_root: only rank 0 holds the table
+        ok = rank != 0
+    else:
+        fb, fo = synth.query_batch(ref_text, q, m)
+        exp = o.query_batch(ref_text, o.sais(ref_text).astype(np.uint32), 0xFFFFFFFF, (fb, fo), threads=1)
+        ok = np.array_equal(got["first"], exp["first"]) and np.array_equal(got["second"], exp["second"])
     np.save(os.path.join(tmp, f"r{rank}.npy"), np.array([int(ok), lo, hi]))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("q", [1001, 7, 1])
-def test_sharded_query_world2_gloo(tmp_path, q):
+@pytest.mark.parametrize("q,chunks,mode", [(1001, 1, "all_gather"), (7, 1, "all_gather"), (1, 1, "all_gather"),
+                                           (1001, 4, "all_gather"), (1003, 3, "gather_to_root"), (5, 4, "gather_to_root")])
+def test_sharded_query_world2_gloo(tmp_path, q, chunks, mode):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), q, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), q, str(tmp_path), chunks, mode), nprocs=world, join=True)
     r = [np.load(tmp_path / f"r{k}.npy") for k in range(world)]
     assert all(x[0] == 1 for x in r)
     assert r[0][1] == 0 and r[0][2] == r[1][1] and r[1][2] == q   # contiguous, complete slices

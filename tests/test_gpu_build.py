@@ -300,6 +300,13 @@ def test_build_device64_is_the_libsais64_layout(gpu, oracle, monkeypatch):
             ("words", synth.d2_words(5_000_000), 0, {"SA_HIP_PILOT": "0"}, True), ("words_L20", synth.d2_words(5_000_000), 20, {"SA_HIP_PILOT": "0"}, True),
             ("words_plain", synth.d2_words(5_000_000), 0, {"SA_HIP_NARROW": "0"}, False), ("small", cases.small_texts()["d2_300k"], 0, {}, False),
             ("banana", cases.small_texts()["banana"], 0, {}, False), ("len1", cases.small_texts()["len1"], 0, {}, False)]
+    # fused AND long repeats: the finisher gives up (fin_useful cleared), doubling rounds swap the slot lists many times
+    # while the FIRST list (the slots to patch) has to stay intact
+    rng = np.random.default_rng(9)
+    blocks = np.tile(rng.integers(97, 123, 400_000, dtype=np.uint8), 12)
+    run = synth.d2_words(5_000_000).copy()
+    run[2_000_000:2_060_000] = ord("q")
+    runs += [("blocks", blocks, 0, {"SA_HIP_PILOT": "0"}, True), ("run", run, 0, {"SA_HIP_PILOT": "0"}, True)]
     for name, t, L, env, fused in runs:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -311,6 +318,8 @@ def test_build_device64_is_the_libsais64_layout(gpu, oracle, monkeypatch):
             idx.sync()
             st = idx.build_stats()
             assert bool(st["widen_fused"]) == fused, (name, st)
+            if name in ("blocks", "run"):
+                assert st["doubling_rounds"] > 0, (name, st)
             assert idx.verify() == 0, name
             got = out.cpu().numpy()
             assert np.array_equal(got[:t.size], idx.sa_u32().astype(np.int64)), name

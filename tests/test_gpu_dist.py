@@ -1,0 +1,129 @@
+"""GPU: BASELINE config 4's code path on one MI355X -- RCCL initialisation, index replication without rebuilding
+(sa_hip_index_replica_*), the sharded, pipelined batch (ShardedBatch: search chunk k + 1 while chunk k is gathered) and
+the gather -- run at world size 1 in a FRESH child process (bench.py --exercise-dist: the process initialises torch,
+RCCL and the GPU in the order a torch.distributed.run rank does), and checked here against the ORACLE: the gathered
+ranges against oracle.query_batch over the downloaded suffix array, the suffix array against the oracle's SA-IS.
+The replica entry points are additionally driven directly, in this process, with device-to-device copies as the
+transport.  (World size 2 of the same functions: tests/test_dist_cpu.py on gloo.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from suffixarray_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("mode,chunks,offsets_api", [("all_gather", 4, False), ("gather_to_root", 3, True)])
+def test_config4_path_world1_child_process(gpu, oracle, tmp_path, mode, chunks, offsets_api):
+    n, q, m = 20_000_000, 400_003, 16
+    dump = str(tmp_path / "ranges.npz")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--exercise-dist", "--chars", str(n), "--queries-global", str(q),
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--dist-mode", mode, "--dist-chunks", str(chunks), "--dump", dump]
+    if offsets_api:
+        cmd.append("--offsets-api")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["gate"]["ok"] and line["gate"]["verify_violations"] == 0, line["gate"]
+    assert line["replicate_bytes"] >= 9 * n          # text + SA + narrow keys + directory all travelled
+    # ... and against the oracle, not against the builder's own answers
+    d = np.load(dump)
+    text = synth.d1_uniform27(n)
+    sa = oracle.sais(text).astype(np.uint32)
+    assert np.array_equal(d["sa"], sa)
+    fb, fo = synth.query_batch(text, q, m, seed=0)
+    exp = oracle.query_batch(text, sa, 0xFFFFFFFF, (fb, fo))
+    assert np.array_equal(d["first"], exp["first"]) and np.array_equal(d["second"], exp["second"])
+    hits = ((exp["second"].astype(np.int64) - exp["first"].astype(np.int64) + 1) & 0xFFFFFFFF) > 0
+    assert 0.05 < hits.mean() < 0.95                 # both sub-populations present
+    print("config-4 path, world size 1 (%s, %d chunks): %.2f G queries/s end to end, %.2f in the kernels; replicate %.1f ms for %.0f MB" % (
+        mode, chunks, line["value"] / 1e9, line["search_only_queries_per_s"] / 1e9, line["replicate_ms"], line["replicate_bytes"] / 1e6))
+
+
+def _replicate_locally(gpu, src, n_max):
+    """The replica entry points with torch device-to-device copies as the transport (what RCCL does between GPUs)."""
+    import torch
+    from suffixarray_amd.distributed import device_view
+    dev = torch.device("cuda", 0)
+    dst = gpu.DeviceIndex(n_max, 0)
+    lay = src.replica_layout()
+    sb = src.replica_buffers().items()
+    db = dst.replica_reserve(lay).items()
+    for (sp, nb), (dp, nb2) in zip(sb, db):
+        assert nb == nb2
+        if nb:
+            device_view(dp, nb, torch.uint8, dev).copy_(device_view(sp, nb, torch.uint8, dev))
+    torch.cuda.synchronize()
+    return dst, lay, db
+
+
+def test_replica_answers_like_the_builder_and_the_oracle(gpu, oracle):
+    """Narrow key array (near-random text), u64 key array (word text: 12-character keys), a truncated index and a tiny
+    one: the replica gives the builder's and the oracle's ranges without having built or searched anything itself."""
+    import cases
+    rng = np.random.default_rng(5)
+    runs = [("d1", synth.d1_uniform27(4_600_000), 0, 4), ("words", synth.d2_words(3_000_000), 0, 8),
+            ("words_L20", synth.d2_words(1_000_000), 20, 8), ("tiny", np.frombuffer(b"abracadabra", np.uint8), 0, 8),
+            ("one", np.frombuffer(b"z", np.uint8), 0, 0)]
+    for name, text, L, key_bytes in runs:
+        with gpu.DeviceIndex(text.size, 0) as src:
+            src.build(text, L)
+            dst, lay, _ = _replicate_locally(gpu, src, text.size)
+            try:
+                assert lay.n == text.size and lay.key_bytes == key_bytes, (name, lay.key_bytes)
+                dst.replica_commit()
+                pats = cases.query_patterns(text, 2000, rng)
+                got = dst.query_batch(pats)
+                assert np.array_equal(got, src.query_batch(pats)), name
+                sa = src.sa_u32()
+                assert np.array_equal(dst.sa_u32(), sa)
+                assert np.array_equal(got, oracle.query_batch(text, sa, L if L else 0xFFFFFFFF, pats)), name
+                assert np.array_equal(dst.freq(), src.freq()) and dst.max_suffix_length == L
+            finally:
+                dst.close()
+
+
+def test_replica_commit_refuses_what_would_send_the_search_out_of_bounds(gpu):
+    import torch
+    from suffixarray_amd.distributed import device_view
+    text = synth.d1_uniform27(4_300_000)
+    dev = torch.device("cuda", 0)
+    with gpu.DeviceIndex(text.size, 0) as src:
+        src.build(text)
+        dst, lay, db = _replicate_locally(gpu, src, text.size)
+        device_view(db[1][0], text.size, torch.int32, dev)[12345] = -7            # an SA entry >= n
+        torch.cuda.synchronize()
+        with pytest.raises(gpu.SaHipError):
+            dst.replica_commit()
+        with pytest.raises(gpu.SaHipError):
+            dst.query_batch([b"abc"])                                              # not searchable
+        with pytest.raises(gpu.SaHipError):
+            dst.replica_commit()                                                   # nothing reserved any more
+        dst.close()
+        dst, lay, db = _replicate_locally(gpu, src, text.size)
+        device_view(db[3][0], int(lay.dir_entries), torch.int32, dev)[-1] = 17     # the directory's end marker
+        torch.cuda.synchronize()
+        with pytest.raises(gpu.SaHipError):
+            dst.replica_commit()
+        dst.close()
+        with gpu.DeviceIndex(1000, 0) as small:
+            with pytest.raises(gpu.SaHipError):
+                small.replica_reserve(lay)                                         # beyond the handle's capacity

@@ -262,8 +262,115 @@ def test_save_load_roundtrip(gpu, tmp_path):
     d = SuffixArray.load(str(tmp_path / "idx_csv"))
     assert c.query_records("netflix") == d.query_records("netflix") and len(d.query_records("netflix")) == 2
     assert d.query_records("acme, inc")[0]["id"] == "2"
+    assert len(d.query_records("netflix", k=10**9)) == 2        # k = "all" sizes nothing by k
     for x in (a, b, c, d):
         x.close()
+
+
+def _saved_arrays(directory):
+    return (np.fromfile(os.path.join(directory, "text.u8"), dtype=np.uint8), np.fromfile(os.path.join(directory, "sa.u32"), dtype=np.uint32))
+
+
+def test_loaded_documents_index_against_the_oracle(gpu, oracle, tmp_path):
+    """after load() nothing is compared with the index it came from -- the loaded index answers a pattern
+    batch exactly as the oracle does on the SAVED text and suffix array, the saved array is the oracle's truncated
+    suffix array of the saved text, and records come back as a plain scan of the documents finds them (>= 1e6 characters)."""
+    from suffixarray_amd import SuffixArray, synth
+    text = synth.d2_words(1_300_000)
+    docs = [d.title() for d in bytes(text).decode().split("\n")]          # mixed case: the index lower-cases
+    L = 24
+    a = SuffixArray(documents=docs, max_suffix_length=L)
+    a.save(str(tmp_path / "idx"))
+    a.close()
+    b = SuffixArray.load(str(tmp_path / "idx"))
+    t, sa = _saved_arrays(str(tmp_path / "idx"))
+    assert t.size >= 1_000_000 and bytes(t) == "\n".join(docs).lower().encode()
+    assert np.array_equal(sa, oracle.truncated_sa(t, L))
+    rng = np.random.default_rng(8)
+    pats = cases.query_patterns(t, 3000, rng)
+    pats = [p for p in pats if p == p.lower() and b"\0" not in p]         # query_ranges lower-cases what it is given
+    got = b.query_ranges([bytes(p) for p in pats])
+    exp = oracle.query_batch(t, sa, L, pats)
+    assert np.array_equal(got["first"], exp["first"]) and np.array_equal(got["second"], exp["second"])
+    assert b._index.verify() == 0
+    low = [d.lower() for d in docs]
+    for q in ["the", docs[17][:9], docs[-1][2:12].upper(), "zzzzzq", docs[5]]:
+        exp_rows = [d for d, l in zip(docs, low) if q.lower()[:L] in l]
+        got_rows = b.query_records(q, k=10**9)
+        assert sorted(got_rows) == sorted(exp_rows), q
+    b.close()
+
+
+def test_loaded_csv_index_against_the_oracle_and_refusals(gpu, oracle, tmp_path):
+    """The same for a CSV-mode index of 120 000 rows; then what load() must refuse: a truncated array file, a row table
+    that does not ascend, a suffix array with an entry >= n, a CSV file that changed after the index was saved."""
+    import json
+    import shutil
+    from suffixarray_amd import SuffixArray
+    from suffixarray_amd.csv_ingest import extract_column
+    path = tmp_path / "companies.csv"
+    gpu.synth_csv(str(path), 120_000, 3)
+    L = 32
+    a = SuffixArray(csv_file=str(path), search_column="company_name", max_suffix_length=L)
+    good = str(tmp_path / "idx")
+    a.save(good)
+    a.close()
+    b = SuffixArray.load(good)
+    t, sa = _saved_arrays(good)
+    col = extract_column(str(path), "company_name")
+    assert bytes(t) == bytes(col.text)
+    assert np.array_equal(sa, oracle.truncated_sa(t, L))
+    names = bytes(t).split(b"\n")[:-1]
+    rng = np.random.default_rng(2)
+    pats = [names[i] for i in rng.integers(0, len(names), 1500)] + [names[i][1:8] for i in rng.integers(0, len(names), 500)] + [b"zzqq", b", inc."]
+    got = b.query_ranges([p.decode() for p in pats])
+    exp = oracle.query_batch(t, sa, L, pats)
+    assert np.array_equal(got["first"], exp["first"]) and np.array_equal(got["second"], exp["second"])
+    for q in [names[5].decode(), names[77].decode()[:5], "llc"]:
+        ids = {int(r["id"]) for r in b.query_records(q, k=10**9)}
+        assert ids == {i + 1 for i, nm in enumerate(names) if q.encode()[:L] in nm}, q
+    b.close()
+
+    def variant(name, mutate):
+        d = str(tmp_path / name)
+        shutil.copytree(good, d)
+        mutate(d)
+        return d
+
+    def truncate(d):
+        with open(os.path.join(d, "sa.u32"), "r+b") as f:
+            f.truncate(os.path.getsize(os.path.join(d, "sa.u32")) - 4096)
+
+    def scramble_rows(d):
+        r = np.fromfile(os.path.join(d, "row_file_offsets.u64"), dtype=np.uint64)
+        r[1000], r[2000] = r[2000], r[1000]
+        r.tofile(os.path.join(d, "row_file_offsets.u64"))
+
+    def bad_entry(d):
+        s = np.fromfile(os.path.join(d, "sa.u32"), dtype=np.uint32)
+        s[12345] = s.size + 5
+        s.tofile(os.path.join(d, "sa.u32"))
+
+    with pytest.raises(ValueError, match="truncated"):
+        SuffixArray.load(variant("trunc", truncate))
+    with pytest.raises((RuntimeError, ValueError), match="ascend"):
+        SuffixArray.load(variant("rows", scramble_rows))
+    with pytest.raises(RuntimeError, match=">= n"):
+        SuffixArray.load(variant("entry", bad_entry))
+    # the CSV file changes after the index was saved: same size, other modification time; then another size
+    st = os.stat(path)
+    os.utime(path, ns=(st.st_atime_ns, st.st_mtime_ns + 5_000_000_000))
+    with pytest.raises(ValueError, match="changed"):
+        SuffixArray.load(good)
+    os.utime(path, ns=(st.st_atime_ns, st.st_mtime_ns))
+    SuffixArray.load(good).close()
+    with open(path, "ab") as f:
+        f.write(b"120001,late arrival llc,US\n")
+    os.utime(path, ns=(st.st_atime_ns, st.st_mtime_ns))
+    with pytest.raises(ValueError, match="changed"):
+        SuffixArray.load(good)
+    meta = json.load(open(os.path.join(good, "meta.json")))
+    assert meta["version"] == 3 and meta["csv_size"] == st.st_size
 
 
 def test_api_edge_cases(gpu):

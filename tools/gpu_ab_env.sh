@@ -2,7 +2,7 @@
 # A/B of one diagnostic switch on one box: tools/gpu_ab_env.sh VAR v1,v2,... [steps] [rounds]
 # alternates bench runs (no CPU baseline) with VAR set to each value and prints build / query / per-kernel pass times
 var=$1; vals=$(echo ${2:-"1,0"} | tr "," " "); steps=${3:-5}; rounds=${4:-2}
-export TMPDIR=/tmp
+export TMPDIR=/tmp SA_HIP_DIAG=1
 for r in $(seq $rounds); do for m in $vals; do
   env $var=$m timeout -k 10 200 python bench.py --steps $steps --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json

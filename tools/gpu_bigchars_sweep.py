@@ -1,5 +1,6 @@
 """Characters per global round while the finisher is at work (SA_HIP_BIG_ROUND_CHARS): python3 tools/gpu_bigchars_sweep.py"""
 import os, subprocess, sys
+os.environ.setdefault("SA_HIP_DIAG", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for kind, n, L in (("names", "900000000", "32"), ("words", "100000000", "0"), ("names", "100000000", "0")):
     for pilot in ("1", "0"):

@@ -1,5 +1,6 @@
 """Sweep of the group finisher's knobs (one box): python3 tools/gpu_fin_sweep.py"""
 import os, subprocess, sys
+os.environ.setdefault("SA_HIP_DIAG", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 n = sys.argv[1] if len(sys.argv) > 1 else "100000000"
 for pilot in ("0", "1"):

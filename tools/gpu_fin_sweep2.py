@@ -1,5 +1,6 @@
 """Tile capacity / workgroup size of the group finisher (libraries built with -DSA_FIN_CAP / -DSA_FIN_ITEMS): python3 tools/gpu_fin_sweep2.py"""
 import os, subprocess, sys, glob
+os.environ.setdefault("SA_HIP_DIAG", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 libs = [("default", os.path.join(ROOT, "suffixarray_amd", "libsa_hip.so"))] + [(os.path.basename(p), p) for p in sorted(glob.glob(os.path.join(ROOT, "tools", "libsa_fin_*.so")))]
 for kind, L in (("words", "0"), ("names", "32")):

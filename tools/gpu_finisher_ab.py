@@ -1,6 +1,7 @@
 """A/B of the in-LDS group finisher and of the initial key length on refinement-heavy texts (one box, one process):
     python3 tools/gpu_finisher_ab.py [n]"""
 import os
+os.environ.setdefault("SA_HIP_DIAG", "1")
 import subprocess
 import sys
 

@@ -1,5 +1,6 @@
 """Initial key length on refinement-heavy text at config-5 scale (one box): python3 tools/gpu_k0_sweep.py [kind] [n] [L]"""
 import os, subprocess, sys
+os.environ.setdefault("SA_HIP_DIAG", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 kind = sys.argv[1] if len(sys.argv) > 1 else "names"
 n = sys.argv[2] if len(sys.argv) > 2 else "900000000"

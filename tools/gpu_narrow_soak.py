@@ -1,6 +1,7 @@
 """Randomized soak of the narrow-record sort: random alphabets / skews / sizes / key lengths (<= 40 bits), full and
 truncated, text-sourced and key-sourced top-digit pass, each against the 12-byte-record plan and the device sufcheck."""
 import os, sys
+os.environ.setdefault("SA_HIP_DIAG", "1")
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -4,6 +4,7 @@ with the in-LDS group finisher on and off and the tile-local round sort on and o
 SA_HIP_LOCAL_ROUNDS), with random initial key lengths: identical suffix arrays, each verified on the device.
     python3 tools/gpu_round_soak.py [seed] [cases]"""
 import os, sys
+os.environ.setdefault("SA_HIP_DIAG", "1")
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,5 +1,6 @@
 """Build latency of small inputs (launch-bound): device time and host wall time of the second build on a warm handle."""
 import os, sys, time
+os.environ.setdefault("SA_HIP_DIAG", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
