@@ -407,21 +407,81 @@ def run_single(args, torch, _capi, synth, dev, device):
         total_bytes = radix_bytes + other * N * steps
         line["whole_build"] = {"bytes_per_char_model": total_bytes / (N * steps), "achieved": total_bytes / (total_ms / 1e3) / 1e9,
                                "unit": "GB/s", "frac": total_bytes / (total_ms / 1e3) / HBM_PEAK}
+    gpu_sa64 = sa64_t.cpu().numpy() if not (args.no_cpu_baseline and args.no_secondary) else None
+    del sa64_t
     if not args.no_cpu_baseline:
-        gpu_sa64 = sa64_t.cpu().numpy()
-        del sa64_t
         base, equal = cpu_baseline(text, q_buf, q_off, gpu_sa64, args.cpu_one_thread_chars)
-        del gpu_sa64
         line["cpu_baseline"] = base
         if equal is not None:
             gate["sa64_equals_reference_libsais64"] = equal
     gate["ok"] = bool(violations == 0 and gate.get("sa64_equals_reference_libsais64", True))
     idx.close()
-    del text
     if not args.no_secondary:
         torch.cuda.empty_cache()
+        dropin = dropin_calls(_capi, torch, dev, text, gpu_sa64)
+        del gpu_sa64, text
         line["secondary"] = secondary_builds(_capi, synth, device)
+        line["secondary"]["dropin"] = dropin
     return line
+
+
+def dropin_calls(_capi, torch, dev, text, gpu_sa64):
+    """The libsais-call-compatible entry points as a caller of the reference would use them (main.c:70-76): host
+    pointers in, host suffix array out -- wall time of sa_hip_libsais64(T, SA, N) at the headline size and of
+    sa_hip_libsais(T, SA, 1e8), cold (workspace released: device buffers + pinned slabs are allocated inside the call) and
+    warm, with the library's own breakdown and the PCIe floor of the bytes that have to cross (measured with pinned
+    1 GiB copies on this box).  Never part of `value`."""
+    out = {}
+    n = text.size
+    # PCIe floor: what a pinned copy of the same bytes takes
+    pin = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
+    devbuf = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    bw = {}
+    for name, (dst, src) in (("h2d", (devbuf, pin)), ("d2h", (pin, devbuf))):
+        dst.copy_(src, non_blocking=True); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dst.copy_(src, non_blocking=True); torch.cuda.synchronize()
+        bw[name] = (1 << 30) / (time.perf_counter() - t0)
+    del pin, devbuf
+    torch.cuda.empty_cache()
+    out["pcie_pinned_gbps"] = {k: v / 1e9 for k, v in bw.items()}
+
+    def run(label, fn, t, width, check):
+        _capi.release_workspace()
+        recs = []
+        for kind in ("cold", "warm", "warm"):
+            sa = np.empty(t.size, dtype=np.int64 if width == 8 else np.int32)   # untouched pages, as a caller's malloc would be
+            t0 = time.perf_counter()
+            rc = fn(t.ctypes.data, sa.ctypes.data, t.size, 0, None)
+            dt = time.perf_counter() - t0
+            assert rc == 0, rc
+            b = _capi.last_call_breakdown()
+            recs.append((kind, dt, b))
+        floor = t.size / bw["h2d"] + 4 * t.size / bw["d2h"]
+        warm = min(recs[1:], key=lambda r: r[1])
+        out[label] = {"n_chars": int(t.size), "cold_s": recs[0][1], "warm_s": warm[1], "chars_per_s_warm": t.size / warm[1],
+                      "pcie_floor_s": floor, "pcie_floor_note": "text up (n bytes) + suffix array down as u32 (4n bytes) at the pinned-copy rates above; "
+                                                               "the int64 form is widened by host threads while the slabs arrive",
+                      "breakdown_cold_ms": {k: recs[0][2][k] for k in ("workspace_ms", "upload_ms", "build_ms", "build_device_ms", "download_ms", "total_ms")},
+                      "breakdown_warm_ms": {k: warm[2][k] for k in ("workspace_ms", "upload_ms", "build_ms", "build_device_ms", "download_ms", "total_ms")},
+                      "equals_device_build": check(sa)}
+        del sa
+
+    lib = _capi.lib()
+    run("sa_hip_libsais64_n1e9" if n == 1_000_000_000 else f"sa_hip_libsais64_n{n}", lib.sa_hip_libsais64, text, 8,
+        lambda sa: bool(np.array_equal(sa, gpu_sa64)) if gpu_sa64 is not None else None)
+    m = min(n, 100_000_000)
+    t1 = np.ascontiguousarray(text[:m])
+    if m == n and gpu_sa64 is not None:
+        chk = lambda sa: bool(np.array_equal(sa, gpu_sa64.astype(np.int32)))
+    else:
+        with _capi.DeviceIndex(m, 0) as ix:
+            ix.build(t1)
+            ref32 = ix.sa_u32().view(np.int32).copy()
+        chk = lambda sa: bool(np.array_equal(sa, ref32))
+    run(f"sa_hip_libsais_n{m}", lib.sa_hip_libsais, t1, 4, chk)
+    _capi.release_workspace()
+    return out
 
 
 def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):

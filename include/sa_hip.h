@@ -66,6 +66,26 @@ int64_t sa_hip_libsais64(const uint8_t* T, int64_t* SA, int64_t n, int64_t fs, i
 /* replaces libsais64_omp (libsais64.h:86, libsais64.c:6783). */
 int64_t sa_hip_libsais64_omp(const uint8_t* T, int64_t* SA, int64_t n, int64_t fs, int64_t* freq, int64_t threads);
 
+/* The four calls above (and sa_hip_construct_truncated_suffix_array) share ONE process-level workspace: a device index
+ * whose buffers are allocated on the first call and grow on demand (about 18 bytes of HBM per character of the
+ * largest text seen) and 512 MB of pinned host slabs through which the text goes up and the suffix array comes down
+ * (as u32 over PCIe, widened to int64 by host threads for the libsais64 forms).  Calls are serialised on it. */
+typedef struct sa_hip_call_breakdown {
+    uint64_t n;
+    uint32_t workspace_reused;   /* 1: no device or pinned allocation in this call                           */
+    uint32_t pad_;
+    double   total_ms;           /* wall time of the call                                                   */
+    double   workspace_ms;       /* creating / growing the workspace                                        */
+    double   upload_ms;          /* text: pageable host memory -> pinned slabs -> HBM                        */
+    double   build_ms;           /* wall time of the device build incl. its host synchronisations           */
+    double   build_device_ms;    /* ... HIP-event time of the same                                          */
+    double   download_ms;        /* suffix array: HBM -> pinned slabs -> (widened into) the caller's array  */
+} sa_hip_call_breakdown;
+/* Where the time of the last of those calls in this process went. */
+int sa_hip_last_call_breakdown(sa_hip_call_breakdown* out);
+/* Free the shared workspace (device buffers and pinned slabs); the next call allocates it again. */
+void sa_hip_release_workspace(void);
+
 /* ---- (2) truncated construction, engine.c-call-compatible ------------------------------- */
 
 /* replaces construct_truncated_suffix_array (engine.h:213, engine.c:837-866).

@@ -18,6 +18,7 @@ UINT32_MAX = 0xFFFFFFFF
 # every symbol include/sa_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "sa_hip_libsais", "sa_hip_libsais_omp", "sa_hip_libsais64", "sa_hip_libsais64_omp",
+    "sa_hip_last_call_breakdown", "sa_hip_release_workspace",
     "sa_hip_construct_truncated_suffix_array", "sa_hip_get_substring_positions",
     "sa_hip_device_count", "sa_hip_index_create", "sa_hip_index_destroy", "sa_hip_index_build",
     "sa_hip_index_build_device", "sa_hip_index_build_device64", "sa_hip_index_load", "sa_hip_index_load_device", "sa_hip_index_n",
@@ -73,6 +74,15 @@ class QueryStats(C.Structure):
                 ("pad_", C.c_uint32)]
 
 
+class CallBreakdown(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("workspace_reused", C.c_uint32), ("pad_", C.c_uint32), ("total_ms", C.c_double),
+                ("workspace_ms", C.c_double), ("upload_ms", C.c_double), ("build_ms", C.c_double), ("build_device_ms", C.c_double),
+                ("download_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad_"}
+
+
 class ReplicaLayout(C.Structure):
     """sa_hip_replica_layout: what a replica must know about the index it copies (travels as bytes)."""
     _fields_ = [("n", C.c_uint64), ("max_suffix_length", C.c_uint32), ("key_bytes", C.c_uint32), ("bits_per_symbol", C.c_uint32),
@@ -116,6 +126,10 @@ def lib():
     L.sa_hip_libsais64.argtypes = [vp, vp, i64, i64, vp]
     L.sa_hip_libsais64_omp.restype = i64
     L.sa_hip_libsais64_omp.argtypes = [vp, vp, i64, i64, vp, i64]
+    L.sa_hip_last_call_breakdown.restype = C.c_int
+    L.sa_hip_last_call_breakdown.argtypes = [C.POINTER(CallBreakdown)]
+    L.sa_hip_release_workspace.restype = None
+    L.sa_hip_release_workspace.argtypes = []
     L.sa_hip_construct_truncated_suffix_array.restype = C.c_int
     L.sa_hip_construct_truncated_suffix_array.argtypes = [vp, C.POINTER(SuffixArrayStruct)]
     L.sa_hip_get_substring_positions.restype = PairU32
@@ -440,6 +454,17 @@ class DeviceIndex:
 
 
 # -- libsais- / engine-compatible one-shot wrappers ----------------------------------------------
+
+def last_call_breakdown():
+    """Where the time of the last libsais-compatible one-shot call of this process went (sa_hip_call_breakdown)."""
+    b = CallBreakdown()
+    check(lib().sa_hip_last_call_breakdown(C.byref(b)))
+    return b.as_dict()
+
+
+def release_workspace():
+    lib().sa_hip_release_workspace()
+
 
 def libsais(text, want_freq=False):
     t = as_u8(text)

@@ -12,6 +12,8 @@
 #include "sa_query.hpp"
 #include "csv_ingest.hpp"
 #include "records.hpp"
+#include "host_io.hpp"
+#include <chrono>
 
 using namespace sa;
 
@@ -883,22 +885,82 @@ void sa_hip_free_suffix_array(sa_hip_SuffixArray_struct* s) {
 }
 
 // ---- libsais-call-compatible wrappers --------------------------------------------------------------
+// Host pointers in, host suffix array out.  One process-level workspace serves all of them (host_io.hpp): a cached
+// index handle whose device buffers are allocated once and grow on demand, and a ring of pinned slabs for both legs
+// over PCIe.  sa_hip_release_workspace() gives the memory back; sa_hip_last_call_breakdown() tells where the time of the
+// last call went.
 
-static int build_to_host(const uint8_t* T, uint64_t n, uint32_t L, TempIndex& t) {
-    int rc = sa_hip_index_create(&t.idx, n, 0);
+extern "C++" {
+namespace {
+struct OneShot {
+    std::mutex mu;
+    sa_hip_index* idx = nullptr;
+    PinnedRing ring;
+    sa_hip_call_breakdown last{};
+} g_oneshot;
+
+double ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// OUT = uint32_t / int32_t (libsais layout) or int64_t (libsais64 layout)
+template <typename OUT, typename FREQ>
+int oneshot_build(const uint8_t* T, uint64_t n, uint32_t L, OUT* out, FREQ* freq) {
+    OneShot& g = g_oneshot;
+    std::lock_guard<std::mutex> lock(g.mu);
+    const auto t_all = std::chrono::steady_clock::now();
+    sa_hip_call_breakdown bd{};
+    bd.n = n;
+    int rc = 0;
+    // workspace: reuse the cached handle when it is large enough
+    auto t0 = std::chrono::steady_clock::now();
+    bd.workspace_reused = (g.idx && g.idx->b.n_max >= n && g.ring.ready) ? 1u : 0u;
+    if (g.idx && g.idx->b.n_max < n) { sa_hip_index_destroy(g.idx); g.idx = nullptr; }
+    if (!g.idx && (rc = sa_hip_index_create(&g.idx, n ? n : 1, 0))) return rc;
+    sa_hip_index* idx = g.idx;
+    std::lock_guard<std::mutex> ilock(idx->mu);
+    if ((rc = set_device(idx->device))) return rc;
+    if ((rc = g.ring.init())) return rc;
+    bd.workspace_ms = ms_since(t0);
+    t0 = std::chrono::steady_clock::now();
+    if ((rc = ring_upload(g.ring, idx->stream, idx->device, idx->b.text.p, T, (size_t)n))) return rc;
+    bd.upload_ms = ms_since(t0);
+    t0 = std::chrono::steady_clock::now();
+    idx->has_index = false;
+    idx->widen_ms = 0.0;
+    rc = idx->b.build(n, L);
+    idx->has_index = (rc == 0);
     if (rc) return rc;
-    return sa_hip_index_build(t.idx, T, n, L);
+    SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+    bd.build_ms = ms_since(t0);
+    bd.build_device_ms = idx->b.stats.total_ms;
+    t0 = std::chrono::steady_clock::now();
+    if ((rc = ring_download<OUT>(g.ring, idx->device, idx->b.sa, out, (size_t)n))) return rc;
+    bd.download_ms = ms_since(t0);
+    if (freq) for (int c = 0; c < 256; ++c) freq[c] = (FREQ)idx->b.freq[c];
+    bd.total_ms = ms_since(t_all);
+    g.last = bd;
+    return 0;
+}
+}  // namespace
+}  // extern "C++"
+
+int sa_hip_last_call_breakdown(sa_hip_call_breakdown* out) {
+    if (!out) return fail(SA_HIP_EINVAL, "sa_hip_last_call_breakdown: NULL argument");
+    std::lock_guard<std::mutex> lock(g_oneshot.mu);
+    *out = g_oneshot.last;
+    return 0;
+}
+
+void sa_hip_release_workspace(void) {
+    std::lock_guard<std::mutex> lock(g_oneshot.mu);
+    if (g_oneshot.idx) { (void)hipSetDevice(g_oneshot.idx->device); sa_hip_index_destroy(g_oneshot.idx); g_oneshot.idx = nullptr; }
+    g_oneshot.ring.destroy();
 }
 
 int32_t sa_hip_libsais_omp(const uint8_t* T, int32_t* SA, int32_t n, int32_t fs, int32_t* freq, int32_t threads) {
     if (T == nullptr || SA == nullptr || n < 0 || fs < 0 || threads < 0) return fail(SA_HIP_EINVAL, "sa_hip_libsais: invalid arguments");
-    TempIndex t;
-    int rc = build_to_host(T, (uint64_t)n, 0, t);
-    if (rc) return rc;
-    rc = sa_hip_index_get_sa_u32(t.idx, reinterpret_cast<uint32_t*>(SA));
-    if (rc) return rc;
-    if (freq) for (int c = 0; c < 256; ++c) freq[c] = (int32_t)t.idx->b.freq[c];
-    return 0;
+    return oneshot_build<int32_t, int32_t>(T, (uint64_t)n, 0, SA, freq);
 }
 
 int32_t sa_hip_libsais(const uint8_t* T, int32_t* SA, int32_t n, int32_t fs, int32_t* freq) {
@@ -908,13 +970,7 @@ int32_t sa_hip_libsais(const uint8_t* T, int32_t* SA, int32_t n, int32_t fs, int
 int64_t sa_hip_libsais64_omp(const uint8_t* T, int64_t* SA, int64_t n, int64_t fs, int64_t* freq, int64_t threads) {
     if (T == nullptr || SA == nullptr || n < 0 || fs < 0 || threads < 0) return fail(SA_HIP_EINVAL, "sa_hip_libsais64: invalid arguments");
     if ((uint64_t)n > 0xFFFFFFFEull) return fail(SA_HIP_EINVAL, "sa_hip_libsais64: n exceeds 2^32 - 2 (single-GPU 32-bit pipeline)");
-    TempIndex t;
-    int rc = build_to_host(T, (uint64_t)n, 0, t);
-    if (rc) return rc;
-    rc = sa_hip_index_get_sa_i64(t.idx, SA);
-    if (rc) return rc;
-    if (freq) for (int c = 0; c < 256; ++c) freq[c] = (int64_t)t.idx->b.freq[c];
-    return 0;
+    return oneshot_build<int64_t, int64_t>(T, (uint64_t)n, 0, SA, freq);
 }
 
 int64_t sa_hip_libsais64(const uint8_t* T, int64_t* SA, int64_t n, int64_t fs, int64_t* freq) {
@@ -931,10 +987,7 @@ int sa_hip_construct_truncated_suffix_array(const char* text, sa_hip_SuffixArray
         for (uint32_t i = 0; i < s->n; ++i) s->suffix_array[i] = i;
         return 0;
     }
-    TempIndex t;
-    int rc = build_to_host(reinterpret_cast<const uint8_t*>(text), s->n, s->max_suffix_length, t);
-    if (rc) return rc;
-    return sa_hip_index_get_sa_u32(t.idx, s->suffix_array);
+    return oneshot_build<uint32_t, uint64_t>(reinterpret_cast<const uint8_t*>(text), s->n, s->max_suffix_length, s->suffix_array, nullptr);
 }
 
 sa_hip_pair_u32 sa_hip_get_substring_positions(const char* str, const sa_hip_SuffixArray_struct* s, const char* substring) {

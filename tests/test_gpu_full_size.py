@@ -31,6 +31,36 @@ def test_config2_n1e8_bit_exact(gpu, oracle):
     assert np.array_equal(sa, exp), (how, st)
 
 
+def test_dropin_libsais_calls_n1e8_memcmp_equal(gpu, oracle):
+    """The libsais-call-compatible entry points (host pointers in, host suffix array out; libsais.h:84, libsais64.h:61)
+    at config 2's size: int64 and int32 results equal the CPU run's byte for byte; freq = the byte histogram
+    (libsais.c:1363-1371); the second call reuses the process-level workspace; the breakdown adds up."""
+    from suffixarray_amd import synth
+    t = synth.d1_uniform27(100_000_000)
+    exp, how = _cpu_sa(t, oracle)
+    gpu.release_workspace()
+    sa64, f64 = gpu.libsais64(t, want_freq=True)
+    cold = gpu.last_call_breakdown()
+    assert sa64.dtype == np.int64 and np.array_equal(sa64, exp.astype(np.int64)), how
+    assert np.array_equal(f64, np.bincount(t, minlength=256))
+    sa32, f32 = gpu.libsais(t, want_freq=True)
+    warm = gpu.last_call_breakdown()
+    assert sa32.dtype == np.int32 and np.array_equal(sa32, exp.view(np.int32)), how
+    assert np.array_equal(f32, np.bincount(t, minlength=256))
+    assert cold["workspace_reused"] == 0 and warm["workspace_reused"] == 1 and warm["n"] == t.size
+    for b in (cold, warm):
+        parts = b["workspace_ms"] + b["upload_ms"] + b["build_ms"] + b["download_ms"]
+        assert parts <= b["total_ms"] * 1.02 + 1.0 and b["build_device_ms"] <= b["build_ms"] + 0.5, b
+    # a smaller text on the same workspace, a truncated build through the engine-compatible call, and an empty text
+    small = synth.d2_words(3_000_000)
+    assert np.array_equal(gpu.libsais(small), oracle.sais(small).astype(np.int32))
+    assert np.array_equal(gpu.construct_truncated_suffix_array(small, 16), oracle.truncated_sa(small, 16))
+    assert gpu.libsais64(np.zeros(0, np.uint8)).size == 0
+    gpu.release_workspace()
+    print("drop-in at n = 1e8: libsais64 cold %.0f ms (workspace %.0f), libsais warm %.0f ms = upload %.0f + build %.0f (device %.1f) + download %.0f" % (
+        cold["total_ms"], cold["workspace_ms"], warm["total_ms"], warm["upload_ms"], warm["build_ms"], warm["build_device_ms"], warm["download_ms"]))
+
+
 def test_words_n1e8_verified_and_bit_exact(gpu, oracle):
     from suffixarray_amd import synth
     t = synth.d2_words(100_000_000)
