@@ -230,6 +230,13 @@ int sa_hip_index_set_rows(sa_hip_index* idx, const uint64_t* row_text_starts, ui
  * (engine.c:1364-1388); one per ROW is this library's decision. */
 int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t len, uint32_t k, uint64_t* row_ids,
                             uint32_t* num_rows, sa_hip_pair_u32* range);
+/* The batched form (new surface; per element it is sa_hip_index_query_rows): pattern i = patterns[offsets[i] ..
+ * offsets[i+1]); row_ids[i * k .. i * k + counts[i]) = its distinct rows, ranges[i] (may be NULL) its SA range.  ONE search
+ * launch finds every range and ONE more launch maps every hit of every range to its row (binary search over the row
+ * table in HBM) and de-duplicates per query in LDS (k <= 4096; larger k is served per query on the host): no per-query
+ * synchronisation, one copy back.  Replaces the per-query loop of suffix_array.pyx:221-247 over engine.c:1364-1388. */
+int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_t* offsets, uint64_t Q, uint32_t k,
+                                  uint64_t* row_ids, uint32_t* counts, sa_hip_pair_u32* ranges);
 /* The same for a range that a batched query has already found (sa_hip_query_batch: one launch for all the ranges,
  * then the rows per range). */
 int sa_hip_index_rows_for_range(sa_hip_index* idx, sa_hip_pair_u32 range, uint32_t k, uint64_t* row_ids, uint32_t* num_rows);

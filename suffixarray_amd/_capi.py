@@ -26,7 +26,7 @@ EXPORTS = [
     "sa_hip_index_stream", "sa_hip_index_get_sa_u32", "sa_hip_index_get_sa_i64", "sa_hip_index_widen_device",
     "sa_hip_index_get_freq", "sa_hip_query_batch", "sa_hip_query_batch_device", "sa_hip_query_batch_device_fixed",
     "sa_hip_index_get_sa_range", "sa_hip_index_query_hits", "sa_hip_index_sync", "sa_hip_index_verify", "sa_hip_index_build_stats",
-    "sa_hip_index_set_rows", "sa_hip_index_query_rows", "sa_hip_index_rows_for_range", "sa_hip_csv_index_copy_rows", "sa_hip_index_get_text", "sa_hip_csv_index_create", "sa_hip_csv_index_adopt",
+    "sa_hip_index_set_rows", "sa_hip_index_query_rows", "sa_hip_index_query_rows_batch", "sa_hip_index_rows_for_range", "sa_hip_csv_index_copy_rows", "sa_hip_index_get_text", "sa_hip_csv_index_create", "sa_hip_csv_index_adopt",
     "sa_hip_csv_index_destroy", "sa_hip_csv_index_handle", "sa_hip_csv_index_num_rows", "sa_hip_csv_index_num_columns",
     "sa_hip_csv_index_column_index", "sa_hip_csv_index_column_name", "sa_hip_csv_index_row_tables",
     "sa_hip_get_substring_positions_file", "sa_hip_get_matching_records_file", "sa_hip_get_matching_records", "sa_hip_free_records",
@@ -204,6 +204,8 @@ def lib():
     L.sa_hip_index_set_rows.argtypes = [vp, vp, u64]
     L.sa_hip_index_query_rows.restype = C.c_int
     L.sa_hip_index_query_rows.argtypes = [vp, C.c_char_p, u64, u32, vp, C.POINTER(u32), C.POINTER(PairU32)]
+    L.sa_hip_index_query_rows_batch.restype = C.c_int
+    L.sa_hip_index_query_rows_batch.argtypes = [vp, vp, vp, u64, u32, vp, vp, vp]
     L.sa_hip_index_rows_for_range.restype = C.c_int
     L.sa_hip_index_rows_for_range.argtypes = [vp, PairU32, u32, vp, C.POINTER(u32)]
     L.sa_hip_index_get_text.restype = C.c_int
@@ -444,6 +446,32 @@ class DeviceIndex:
             check(self._lib.sa_hip_query_batch(self._h, buf.ctypes.data if buf.size else None, off.ctypes.data, q,
                                                out.ctypes.data))
         return out[:q]
+
+    def set_rows(self, row_text_starts):
+        r = np.ascontiguousarray(row_text_starts, dtype=np.uint64)
+        check(self._lib.sa_hip_index_set_rows(self._h, r.ctypes.data if r.size else None, r.size))
+
+    def query_rows(self, pattern: bytes, k):
+        """ONE query -> (row ids in SA order of their first hit, (first, second))."""
+        rows = np.empty(max(k, 1), dtype=np.uint64)
+        n = C.c_uint32(0)
+        rng = PairU32()
+        check(self._lib.sa_hip_index_query_rows(self._h, pattern, len(pattern), k, rows.ctypes.data, C.byref(n), C.byref(rng)))
+        return rows[:n.value].copy(), (rng.first, rng.second)
+
+    def query_rows_batch(self, patterns, k):
+        """A batch -> (list of row-id arrays, structured ranges): one search launch + one rows launch."""
+        buf, off = patterns if isinstance(patterns, tuple) else pack_patterns(patterns)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        q = off.size - 1
+        rows = np.empty((max(q, 1), max(k, 1)), dtype=np.uint64)
+        counts = np.zeros(max(q, 1), dtype=np.uint32)
+        ranges = np.zeros(max(q, 1), dtype=PAIR_DTYPE)
+        if q:
+            check(self._lib.sa_hip_index_query_rows_batch(self._h, buf.ctypes.data if buf.size else None, off.ctypes.data, q, k,
+                                                          rows.ctypes.data, counts.ctypes.data, ranges.ctypes.data))
+        return [rows[i, :counts[i]].copy() for i in range(q)], ranges[:q]
 
     def query_batch_device(self, patterns_dev_ptr, offsets_dev_ptr, q, out_dev_ptr):
         check(self._lib.sa_hip_query_batch_device(self._h, patterns_dev_ptr, offsets_dev_ptr, q, out_dev_ptr))

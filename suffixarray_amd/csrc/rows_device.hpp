@@ -1,0 +1,102 @@
+// rows_device.hpp -- hits -> distinct rows on the device, for whole batches.
+//
+// Replaces, by function, the per-hit loop of get_matching_records_file (engine.c:1364-1388: for every hit seek to the
+// enclosing row) and what the reference's Python layer does around it per query (suffix_array.pyx:221-247).  Until
+// round 3 this library found all ranges of a batch in one launch and then looped PER QUERY over synchronous copies of
+// SA slabs + a host binary search + a hash set (records.hpp: distinct_rows).  Here one workgroup per query walks the
+// range SA[first ..] in chunks of 256 hits:
+//     hit -> row            binary search over the row-start table in HBM
+//     row -> first seen?    LDS hash table keyed by row, value = index of the row's FIRST hit (64-bit entries:
+//                           compare-and-swap claims a slot, atomic min keeps the smallest hit index of a row)
+//     new rows, in hit order: ballot prefix over the chunk -> out_rows[query][have ...]
+// until k distinct rows are collected or the range ends -- exactly the rows, in exactly the order, that
+// distinct_rows() returns (tests compare the two).  k <= ROWS_K_MAX; larger k ("all rows") stays on the host path.
+#pragma once
+#include "common.hpp"
+
+namespace sa {
+
+constexpr u32 ROWS_K_MAX = 4096;
+constexpr u32 ROWS_SLOTS_SMALL = 4096;    // k <= 1536: 32 KB of LDS
+constexpr u32 ROWS_K_SMALL = 1536;
+constexpr u32 ROWS_SLOTS_LARGE = 16384;   // k <= 4096: 128 KB of LDS (one workgroup per CU)
+
+struct RowsArgs {
+    const u32* sa;
+    const sa_hip_pair_u32* ranges;   // [q], conventions of get_substring_positions (engine.c:896-898, 916-917)
+    u64 q;
+    const u64* row_starts;           // [num_rows], ascending, row_starts[0] = 0
+    u64 num_rows;
+    u32 k;                           // 1 .. ROWS_K_MAX (and <= what SLOTS allows)
+    u32* out_rows;                   // [q][k]
+    u32* out_counts;                 // [q]
+};
+
+template <u32 SLOTS>
+__global__ __launch_bounds__(256) void rows_kernel(RowsArgs a) {
+    __shared__ unsigned long long s_tab[SLOTS];   // (row + 1) << 32 | index of the row's first hit; 0 = empty
+    __shared__ u32 s_wcnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int SHIFT = 32 - (SLOTS == 4096 ? 12 : 14);
+    static_assert(SLOTS == 4096 || SLOTS == 16384, "table sizes");
+    for (u64 qi = blockIdx.x; qi < a.q; qi += gridDim.x) {
+        const sa_hip_pair_u32 rg = a.ranges[qi];
+        u32 count = 0;
+        if (rg.first != 0xFFFFFFFFu && (u32)(rg.second - rg.first + 1u) != 0u) count = rg.second - rg.first + 1u;   // miss: second = first - 1
+        for (u32 i = tid; i < SLOTS; i += 256) s_tab[i] = 0ull;
+        __syncthreads();
+        u32 have = 0;
+        for (u64 base = 0; base < count && have < a.k; base += 256) {
+            const bool valid = base + (u64)tid < count;
+            const u32 i = (u32)(base + (u64)tid);
+            u32 row = 0, slot = 0;
+            if (valid) {
+                const u64 pos = a.sa[(u64)rg.first + i];
+                u64 lo = 0, hi = a.num_rows;             // first row whose start is > pos
+                while (lo < hi) {
+                    const u64 mid = (lo + hi) >> 1;
+                    if (a.row_starts[mid] <= pos) lo = mid + 1; else hi = mid;
+                }
+                row = (u32)(lo - 1);                     // row_starts[0] = 0 <= pos
+                const unsigned long long key = (unsigned long long)(row + 1u) << 32;
+                slot = (row * 0x9E3779B1u) >> SHIFT;
+                while (true) {
+                    const unsigned long long old = atomicCAS(&s_tab[slot], 0ull, key | i);
+                    if (old == 0ull) break;
+                    if ((old >> 32) == (key >> 32)) { atomicMin(&s_tab[slot], key | i); break; }
+                    slot = (slot + 1u) & (SLOTS - 1u);
+                }
+            }
+            sync_lds();   // LDS atomics above
+            const bool win = valid && (u32)s_tab[slot] == i;   // this hit is the first one of its row
+            const u64 m = __ballot(win);
+            if (lane == 0) s_wcnt[wave] = (u32)__popcll(m);
+            __syncthreads();
+            u32 before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { const u32 c = s_wcnt[w]; if (w < wave) before += c; total += c; }
+            if (win) {
+                const u32 p = have + before + (u32)__popcll(m & lanemask_lt());
+                if (p < a.k) a.out_rows[qi * a.k + p] = row;
+            }
+            have += total;
+            __syncthreads();   // s_wcnt is rewritten by the next chunk
+        }
+        if (tid == 0) a.out_counts[qi] = have < a.k ? have : a.k;
+        __syncthreads();       // the table is cleared for the next query
+    }
+}
+
+inline void launch_rows(hipStream_t stream, const RowsArgs& a) {
+    if (a.q == 0) return;
+    u64 g = a.q;
+    if (a.k <= ROWS_K_SMALL) {
+        if (g > 256u * 8u) g = 256u * 8u;
+        hipLaunchKernelGGL(rows_kernel<ROWS_SLOTS_SMALL>, dim3((u32)g), dim3(256), 0, stream, a);
+    } else {
+        if (g > 256u * 2u) g = 256u * 2u;
+        hipLaunchKernelGGL(rows_kernel<ROWS_SLOTS_LARGE>, dim3((u32)g), dim3(256), 0, stream, a);
+    }
+}
+
+}  // namespace sa

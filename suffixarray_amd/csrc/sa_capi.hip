@@ -13,6 +13,7 @@
 #include "csv_ingest.hpp"
 #include "records.hpp"
 #include "host_io.hpp"
+#include "rows_device.hpp"
 #include <chrono>
 
 using namespace sa;
@@ -40,6 +41,8 @@ struct sa_hip_index {
     double widen_ms = 0.0;                           // < 0: recorded, not yet resolved
     sa_hip_query_stats qstats{};
     std::vector<u64> row_starts;   // sa_hip_index_set_rows: offset of every row (document, CSV field) in the indexed text
+    DevBuf rows_dev;               // the same table in HBM (rows_device.hpp)
+    DevBuf r_rows, r_counts;       // results of the rows kernel (batched form)
     bool receiving = false;        // sa_hip_index_replica_reserve .. _commit: the buffers are being filled by the caller
     sa_hip_replica_layout pending{};
 };
@@ -180,6 +183,7 @@ void sa_hip_index_destroy(sa_hip_index* idx) {
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     idx->b.destroy();
     idx->q_pat.release(); idx->q_off.release(); idx->q_out.release(); idx->widen.release();
+    idx->rows_dev.release(); idx->r_rows.release(); idx->r_counts.release();
     if (idx->qh_host) (void)hipHostFree(idx->qh_host);
     for (int i = 0; i < sa_hip_index::QRING; ++i)
         for (int k = 0; k < 2; ++k) if (idx->q_ev[i][k]) (void)hipEventDestroy(idx->q_ev[i][k]);
@@ -624,6 +628,12 @@ int sa_hip_index_set_rows(sa_hip_index* idx, const uint64_t* row_text_starts, ui
     std::lock_guard<std::mutex> g(idx->mu);
     try { idx->row_starts.assign(row_text_starts, row_text_starts + num_rows); }
     catch (const std::bad_alloc&) { return fail(SA_HIP_ENOMEM, "sa_hip_index_set_rows: out of host memory"); }
+    // ... and in HBM for the rows kernel
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    if ((rc = idx->rows_dev.ensure((size_t)(num_rows ? num_rows : 1) * 8))) return rc;
+    if (num_rows) SA_HIP_CHECK(hipMemcpyAsync(idx->rows_dev.p, row_text_starts, (size_t)num_rows * 8, hipMemcpyHostToDevice, idx->stream));
+    SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
     return 0;
 }
 
@@ -639,6 +649,48 @@ int sa_hip_index_get_text(sa_hip_index* idx, uint8_t* out_host) {
     return 0;
 }
 
+// host path of the record retrieval (records.hpp): k beyond ROWS_K_MAX ("all rows"), and SA_HIP_HOST_ROWS=1 (diagnostic:
+// the tests compare the two paths row for row)
+static bool host_rows_forced() {
+    const char* e = diag_env("SA_HIP_HOST_ROWS");
+    return e && atoi(e) != 0;
+}
+
+// (idx->mu held) ONE query: search + rows kernel through the pinned block, one synchronisation
+static int query_rows_device_locked(sa_hip_index* idx, const uint8_t* pattern, uint64_t len, uint32_t k, uint64_t* row_ids,
+                                    uint32_t* num_rows, sa_hip_pair_u32* range) {
+    if (len > QH_BYTES - 64 - QH_OFF_PATTERN) return fail(SA_HIP_EINVAL, "sa_hip_index_query_rows: pattern longer than 47 KB");
+    if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_query_rows: no index");
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    if (!idx->qh_host) {
+        SA_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&idx->qh_host), QH_BYTES, hipHostMallocMapped));
+        SA_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&idx->qh_dev), idx->qh_host, 0));
+    }
+    u8* h = idx->qh_host;
+    u8* d = idx->qh_dev;
+    const u64 off[2] = {0, len};
+    memcpy(h + QH_OFF_OFFSETS, off, sizeof off);
+    if (len) memcpy(h + QH_OFF_PATTERN, pattern, len);
+    memset(h + QH_OFF_PATTERN + len, 0, 64);
+    if ((rc = launch_query(idx, d + QH_OFF_PATTERN, reinterpret_cast<const u64*>(d + QH_OFF_OFFSETS), 1,
+                           reinterpret_cast<sa_hip_pair_u32*>(d)))) return rc;
+    RowsArgs a;
+    a.sa = idx->b.sa; a.ranges = reinterpret_cast<const sa_hip_pair_u32*>(d); a.q = 1;
+    a.row_starts = idx->rows_dev.as<u64>(); a.num_rows = idx->row_starts.size(); a.k = k;
+    a.out_rows = reinterpret_cast<u32*>(d + QH_OFF_HITS); a.out_counts = reinterpret_cast<u32*>(d + 8);
+    launch_rows(idx->stream, a);
+    SA_HIP_CHECK(hipGetLastError());
+    SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+    if (range) memcpy(range, h, sizeof *range);
+    u32 n = 0;
+    memcpy(&n, h + 8, 4);
+    const u32* rows = reinterpret_cast<const u32*>(h + QH_OFF_HITS);
+    for (u32 i = 0; i < n; ++i) row_ids[i] = rows[i];
+    *num_rows = n;
+    return 0;
+}
+
 int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t len, uint32_t k, uint64_t* row_ids,
                             uint32_t* num_rows, sa_hip_pair_u32* range) {
     if (!idx || !num_rows || (!row_ids && k) || (!pattern && len)) return fail(SA_HIP_EINVAL, "sa_hip_index_query_rows: NULL argument");
@@ -646,8 +698,10 @@ int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t 
     sa_hip_pair_u32 rg;
     u32 nh = 0;
     std::lock_guard<std::mutex> g(idx->mu);   // the search, the slabs of hits and the row table under ONE acquisition
+    if (k && idx->row_starts.empty()) return fail(SA_HIP_EINVAL, "sa_hip_index_query_rows: no row table (sa_hip_index_set_rows)");
     // more rows than the table holds cannot come back: k = 10^9 ("all") must not size anything
     if ((u64)k > idx->row_starts.size()) k = (u32)idx->row_starts.size();
+    if (k && k <= ROWS_K_MAX && !host_rows_forced()) return query_rows_device_locked(idx, pattern, len, k, row_ids, num_rows, range);
     const u32 cap = k ? std::min<u32>(std::max<u32>(4u * k, 1024u), QH_MAX_HITS) : 0u;
     try {
         std::vector<u32> first(cap ? cap : 1);
@@ -655,7 +709,7 @@ int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t 
         if (rc) return rc;
         if (range) *range = rg;
         const std::vector<u64>& starts = idx->row_starts;
-        if (starts.empty()) return k ? fail(SA_HIP_EINVAL, "sa_hip_index_query_rows: no row table (sa_hip_index_set_rows)") : 0;
+        if (starts.empty()) return 0;
         std::vector<u64> rows;
         rc = distinct_rows(starts, rg, k, first.data(), nh,
                            [&](u64 pos, u64 count, u32* out) { return get_sa_range_locked(idx, pos, count, out); }, rows);
@@ -666,6 +720,69 @@ int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t 
     return 0;
 }
 
+int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_t* offsets, uint64_t Q, uint32_t k,
+                                  uint64_t* row_ids, uint32_t* counts, sa_hip_pair_u32* ranges) {
+    if (!idx || (Q && (!offsets || !counts || (!row_ids && k)))) return fail(SA_HIP_EINVAL, "sa_hip_index_query_rows_batch: NULL argument");
+    if (Q == 0) return 0;
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_query_rows_batch: no index");
+    const u64 total = offsets[Q];
+    if (!patterns && total) return fail(SA_HIP_EINVAL, "sa_hip_index_query_rows_batch: NULL patterns");
+    const u32 k_in = k;
+    if (k && idx->row_starts.empty()) return fail(SA_HIP_EINVAL, "sa_hip_index_query_rows_batch: no row table (sa_hip_index_set_rows)");
+    if ((u64)k > idx->row_starts.size()) k = (u32)idx->row_starts.size();
+    for (u64 i = 0; i < Q; ++i) counts[i] = 0;
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    // ONE search launch for all the ranges
+    if ((rc = idx->q_pat.ensure((size_t)total + 64))) return rc;
+    if ((rc = idx->q_off.ensure((size_t)(Q + 1) * 8))) return rc;
+    if ((rc = idx->q_out.ensure((size_t)Q * sizeof(sa_hip_pair_u32)))) return rc;
+    if (total) SA_HIP_CHECK(hipMemcpyAsync(idx->q_pat.p, patterns, total, hipMemcpyHostToDevice, idx->stream));
+    SA_HIP_CHECK(hipMemsetAsync(idx->q_pat.as<u8>() + total, 0, 64, idx->stream));
+    SA_HIP_CHECK(hipMemcpyAsync(idx->q_off.p, offsets, (size_t)(Q + 1) * 8, hipMemcpyHostToDevice, idx->stream));
+    if ((rc = launch_query(idx, idx->q_pat.as<u8>(), idx->q_off.as<u64>(), Q, idx->q_out.as<sa_hip_pair_u32>()))) return rc;
+    try {
+        std::vector<sa_hip_pair_u32> rg_host;
+        const bool device_rows = k && k <= ROWS_K_MAX && !host_rows_forced();
+        if (ranges || !device_rows) {
+            rg_host.resize(Q);
+            SA_HIP_CHECK(hipMemcpyAsync(rg_host.data(), idx->q_out.p, (size_t)Q * sizeof(sa_hip_pair_u32), hipMemcpyDeviceToHost, idx->stream));
+        }
+        if (device_rows) {
+            // ... ONE rows launch for all the hits -> rows, one copy back: no per-query synchronisation
+            if ((rc = idx->r_rows.ensure((size_t)Q * k * 4))) return rc;
+            if ((rc = idx->r_counts.ensure((size_t)Q * 4))) return rc;
+            RowsArgs a;
+            a.sa = idx->b.sa; a.ranges = idx->q_out.as<sa_hip_pair_u32>(); a.q = Q;
+            a.row_starts = idx->rows_dev.as<u64>(); a.num_rows = idx->row_starts.size(); a.k = k;
+            a.out_rows = idx->r_rows.as<u32>(); a.out_counts = idx->r_counts.as<u32>();
+            launch_rows(idx->stream, a);
+            SA_HIP_CHECK(hipGetLastError());
+            std::vector<u32> rows32((size_t)Q * k);
+            SA_HIP_CHECK(hipMemcpyAsync(counts, idx->r_counts.p, (size_t)Q * 4, hipMemcpyDeviceToHost, idx->stream));
+            SA_HIP_CHECK(hipMemcpyAsync(rows32.data(), idx->r_rows.p, (size_t)Q * k * 4, hipMemcpyDeviceToHost, idx->stream));
+            SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+            for (u64 q = 0; q < Q; ++q)
+                for (u32 i = 0; i < counts[q]; ++i) row_ids[q * k_in + i] = rows32[q * k + i];
+        } else {
+            SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+            if (k) {
+                std::vector<u64> rows;
+                for (u64 q = 0; q < Q; ++q) {
+                    rc = distinct_rows(idx->row_starts, rg_host[q], k, nullptr, 0,
+                                       [&](u64 pos, u64 count, u32* out) { return get_sa_range_locked(idx, pos, count, out); }, rows);
+                    if (rc) return rc;
+                    for (size_t i = 0; i < rows.size(); ++i) row_ids[q * k_in + i] = rows[i];
+                    counts[q] = (u32)rows.size();
+                }
+            }
+        }
+        if (ranges) memcpy(ranges, rg_host.data(), (size_t)Q * sizeof(sa_hip_pair_u32));
+    } catch (const std::bad_alloc&) { return fail(SA_HIP_ENOMEM, "sa_hip_index_query_rows_batch: out of host memory"); }
+    return 0;
+}
+
 int sa_hip_index_rows_for_range(sa_hip_index* idx, sa_hip_pair_u32 range, uint32_t k, uint64_t* row_ids, uint32_t* num_rows) {
     if (!idx || !num_rows || (!row_ids && k)) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: NULL argument");
     *num_rows = 0;
@@ -673,10 +790,11 @@ int sa_hip_index_rows_for_range(sa_hip_index* idx, sa_hip_pair_u32 range, uint32
     if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: no index");
     if (range.first != 0xFFFFFFFFu && (u32)(range.second - range.first + 1u) != 0u &&
         ((u64)range.second >= idx->b.n || range.first > range.second)) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: range outside the suffix array");
+    if (k && idx->row_starts.empty()) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: no row table (sa_hip_index_set_rows)");
     if ((u64)k > idx->row_starts.size()) k = (u32)idx->row_starts.size();
     try {
         const std::vector<u64>& starts = idx->row_starts;
-        if (starts.empty()) return k ? fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: no row table (sa_hip_index_set_rows)") : 0;
+        if (starts.empty()) return 0;
         std::vector<u64> rows;
         int rc = distinct_rows(starts, range, k, nullptr, 0,
                                [&](u64 pos, u64 count, u32* out) { return get_sa_range_locked(idx, pos, count, out); }, rows);

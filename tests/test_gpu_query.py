@@ -373,6 +373,62 @@ def test_loaded_csv_index_against_the_oracle_and_refusals(gpu, oracle, tmp_path)
     assert meta["version"] == 3 and meta["csv_size"] == st.st_size
 
 
+def test_device_rows_equal_host_rows(gpu, monkeypatch):
+    """Record retrieval on the device (rows_device.hpp: one workgroup per query, hits -> rows by binary search over the
+    row table, per-query de-duplication in an LDS hash table, rows in SA order of their first hit) against the host
+    path it replaces (records.hpp: distinct_rows over copied SA slabs) -- the same rows in the same order for every k up to
+    4096 (both table sizes), single query and batch, ranges of a few million hits in a handful of rows included -- and
+    both against a plain scan of the column."""
+    from suffixarray_amd.csv_ingest import extract_column
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "c.csv")
+        gpu.synth_csv(path, 300_000, 11)
+        col = extract_column(path, "company_name")
+    text = np.frombuffer(col.text, dtype=np.uint8)
+    names = bytes(col.text).split(b"\n")[:-1]
+    starts = np.asarray(col.row_text_starts, dtype=np.uint64)
+    rng = np.random.default_rng(6)
+    pats = [names[i] for i in rng.integers(0, len(names), 150)] + [names[i][2:6] for i in rng.integers(0, len(names), 60)]
+    pats += [b"inc", b" ", b"a", b"llc", b"zzqqzz", b"e", names[0], b", inc.", b"\n"]
+    with gpu.DeviceIndex(text.size, 0) as idx:
+        idx.build(text, 32)
+        idx.set_rows(starts)
+        sa = idx.sa_u32()
+        for k in (1, 7, 300, 1000, 1536, 1537, 4096, 5000):
+            monkeypatch.setenv("SA_HIP_HOST_ROWS", "1")
+            host_rows, host_rg = idx.query_rows_batch(pats, k)
+            monkeypatch.delenv("SA_HIP_HOST_ROWS")
+            dev_rows, dev_rg = idx.query_rows_batch(pats, k)
+            assert np.array_equal(host_rg, dev_rg)
+            for p, a, b in zip(pats, host_rows, dev_rows):
+                assert np.array_equal(a, b), (k, p, a[:10], b[:10])
+            for p, b in list(zip(pats, dev_rows))[::7]:
+                one, rg1 = idx.query_rows(p, k)
+                assert np.array_equal(one, b), (k, p)
+        # k = 1000 against a scan: first k distinct rows in hit order
+        for p, rows, rg in zip(pats, dev_rows if False else idx.query_rows_batch(pats, 1000)[0], dev_rg):
+            exp = {i for i, nm in enumerate(names) if p[:32] in nm + b"\n"} if p != b"\n" else set(range(len(names)))
+            got = set(int(r) for r in rows)
+            if len(exp) <= 1000:
+                assert got == exp, p
+            else:
+                assert len(got) == 1000 and got <= exp, p
+            f, s2 = int(rg["first"]), int(rg["second"])
+            if len(exp):
+                hit_rows = np.searchsorted(starts, sa[f:min(s2 + 1, f + 200000)], side="right") - 1
+                _, first_idx = np.unique(hit_rows, return_index=True)
+                order = hit_rows[np.sort(first_idx)][:1000]
+                assert np.array_equal(order[:rows.size], rows[:order.size]), p
+    with gpu.DeviceIndex(100, 0) as idx:
+        idx.build(np.frombuffer(b"abc\nabd\n", np.uint8))
+        with pytest.raises(gpu.SaHipError):
+            idx.query_rows_batch([b"ab"], 5)            # no row table
+        idx.set_rows(np.array([0, 4], dtype=np.uint64))
+        rows, rg = idx.query_rows_batch([b"ab", b"d", b"zz", b""], 10**9)
+        assert [r.tolist() for r in rows] == [[0, 1], [1], [], [0, 1]] or [sorted(r.tolist()) for r in rows] == [[0, 1], [1], [], [0, 1]]
+
+
 def test_api_edge_cases(gpu):
     lib = gpu.lib()
     import ctypes as C
