@@ -31,7 +31,7 @@
 
 namespace sa {
 
-constexpr int NARROW_MAX_PASSES = 4;
+constexpr int NARROW_MAX_PASSES = 6;   // 4 passes of a 32-bit remainder; 2 + 4 of a 48-bit one (radix_narrow48.hpp)
 constexpr int SEG_ITEMS = 24;   // records per thread of the narrow passes: tiles of 512 x 24 = 12288 records
 
 struct SegPlan {              // device resident, written by seg_plan_kernel
@@ -91,8 +91,8 @@ __device__ __forceinline__ u32 seg_bucket_of(const u32* tprefix, u32 f) {
 // histogram of digit [shift, shift + 8) of the narrow keys, per bucket: hist[b][d]; the LDS histogram is kept in
 // SEG_HIST_COPIES lane-selected copies (fewer lanes of a wave on the same counter)
 constexpr int SEG_HIST_COPIES = 4;
-template <int BLOCK, int ITEMS>
-__global__ __launch_bounds__(BLOCK) void seg_hist_kernel(const u32* __restrict__ keys, const SegPlan* __restrict__ plan, int shift,
+template <int BLOCK, int ITEMS, typename KT = u32>
+__global__ __launch_bounds__(BLOCK) void seg_hist_kernel(const KT* __restrict__ keys, const SegPlan* __restrict__ plan, int shift,
                                                          u32 mask, u32* __restrict__ hist, u32 tiles_per_block) {
     constexpr u32 TILE = BLOCK * ITEMS;
     constexpr int CS = RADIX + 1;
@@ -126,11 +126,11 @@ __global__ __launch_bounds__(BLOCK) void seg_hist_kernel(const u32* __restrict__
         if (len == TILE) {   // all loads of the tile in flight before the first LDS atomic
             u32 k[ITEMS];
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) k[j] = keys[start + j * BLOCK + threadIdx.x];
+            for (int j = 0; j < ITEMS; ++j) k[j] = (u32)keys[start + j * BLOCK + threadIdx.x];
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) atomicAdd(&my[(k[j] >> shift) & mask], 1u);
         } else {
-            for (u32 l = threadIdx.x; l < len; l += BLOCK) atomicAdd(&my[(keys[start + l] >> shift) & mask], 1u);
+            for (u32 l = threadIdx.x; l < len; l += BLOCK) atomicAdd(&my[((u32)keys[start + l] >> shift) & mask], 1u);
         }
     }
     flush(cur);
@@ -453,7 +453,8 @@ struct TextPassArgs {
     const u16* map;         // CodeMap::code in device memory
     u64 n;
     int b, k0, begin_bit;   // key = k0 characters of b bits, MSB first, in bits [begin_bit, 64); b <= 8
-    u32* keys_out32;        // (u32)(key >> begin_bit)
+    u32* keys_out32;        // (u32)(key >> begin_bit); EXT: (u32)(key >> (begin_bit + 16))
+    u16* ext_out16;         // EXT (48-bit remainder, radix_narrow48.hpp): (u16)(key >> begin_bit)
     u32* vals_out;          // text position
     SortGeom g;
     const u32* digit_base;  // [NCHUNK][RADIX] of the top digit
@@ -480,7 +481,7 @@ __device__ __forceinline__ void shl_or_inplace(u32& acc, u32 x, int s) {
 
 // (b and k0 stay run-time values: with b = 5, k0 = 8 as compile-time constants the compiler merges a key's eight byte
 // reads into one unaligned ds_read_b64 and the pass gets slower, 4.54 vs 3.69 ms at N = 1e9.)
-template <bool FULL, int BLOCK>
+template <bool FULL, int BLOCK, bool EXT>
 __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 tile, const u32 chunk,
                                               const u32 tile_n, u32* s_keys, u32* s_whist, u32* s_gdelta, u32* s_wsum,
                                               u8* s_code, const u8* s_map) {
@@ -550,10 +551,14 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
             for (int j = 0; j < ITEMS; ++j) shl_or_inplace(lo[j], (u32)cp[j * WAVE], sh);
         }
     }
-    u32 key[ITEMS];   // narrow keys: bits [begin_bit, begin_bit + 32) of hi:lo
+    u32 key[ITEMS];   // narrow keys: bits [begin_bit, begin_bit + 32) of hi:lo (EXT: bits [begin_bit + 16, begin_bit + 48))
+    u32 ext[EXT ? ITEMS : 1];   // EXT: bits [begin_bit, begin_bit + 16)
+    const int kb0 = EXT ? a.begin_bit + 16 : a.begin_bit;
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j)
-        key[j] = (a.begin_bit >= 32) ? (hi[j] >> (a.begin_bit - 32)) : __builtin_amdgcn_alignbit(hi[j], lo[j], (u32)a.begin_bit);
+    for (int j = 0; j < ITEMS; ++j) {
+        key[j] = (kb0 >= 32) ? (hi[j] >> (kb0 - 32)) : __builtin_amdgcn_alignbit(hi[j], lo[j], (u32)kb0);
+        if (EXT) ext[j] = __builtin_amdgcn_alignbit(hi[j], lo[j], (u32)a.begin_bit) & 0xFFFFu;   // begin_bit < 24
+    }
 
     // 2. rank by the top digit (bits 24..31 of hi)
     u32 rd[ITEMS];
@@ -627,6 +632,19 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
         }
     }
     __syncthreads();
+    if (EXT) {   // the low 16 key bits take the same route (the key array's LDS as u16)
+        u16* s_ext = reinterpret_cast<u16*>(s_keys);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (FULL || (woff + j * WAVE) < tile_n) s_ext[pos[j]] = (u16)ext[j];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const u32 p = k * BLOCK + tid;
+            if (FULL || p < tile_n) a.ext_out16[gidx[k]] = s_ext[p];
+        }
+        __syncthreads();
+    }
     u32* s_vals = s_keys;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j)
@@ -640,8 +658,8 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
 }
 
 // 79 VGPRs and 50 KB of LDS: three workgroups (24 waves) per CU
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, (TEXT_ITEMS > 16) ? 4 : 6) void text_top_pass_kernel(TextPassArgs a) {
+template <int BLOCK, bool EXT = false>
+__global__ __launch_bounds__(BLOCK, (TEXT_ITEMS > 16 || EXT) ? 4 : 6) void text_top_pass_kernel(TextPassArgs a) {
     constexpr int WAVES = BLOCK / WAVE;
     constexpr u32 TILE = BLOCK * TEXT_ITEMS;
     __shared__ __attribute__((aligned(16))) u32 s_keys[TILE];
@@ -676,9 +694,9 @@ __global__ __launch_bounds__(BLOCK, (TEXT_ITEMS > 16) ? 4 : 6) void text_top_pas
     const u32 chunk = s_chunk;
     const u64 rest = a.n - (u64)tile * TILE;
     if (rest >= (u64)TILE)
-        text_top_tile<true, BLOCK>(a, tile, chunk, TILE, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
+        text_top_tile<true, BLOCK, EXT>(a, tile, chunk, TILE, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
     else
-        text_top_tile<false, BLOCK>(a, tile, chunk, (u32)rest, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
+        text_top_tile<false, BLOCK, EXT>(a, tile, chunk, (u32)rest, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
 }
 
 // ---- pass 0 of the plain LSD sort straight from the text ---------------------------------------------------
@@ -1032,7 +1050,7 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
         if (src) {
             TextPassArgs t;
             t.text = src->text; t.map = nw.map_dev; t.n = n; t.b = src->b; t.k0 = src->k0; t.begin_bit = begin_bit;
-            t.keys_out32 = reinterpret_cast<u32*>(keysB); t.vals_out = valsB; t.g = g; t.digit_base = ws.base();
+            t.keys_out32 = reinterpret_cast<u32*>(keysB); t.ext_out16 = nullptr; t.vals_out = valsB; t.g = g; t.digit_base = ws.base();
             t.status = ws.status; t.ticket = ws.tickets(); t.epoch = ws.epoch; t.dstat = ws.dstat; t.incl_mask = SA_INCL_MASK;
             if ((rc = ws.timer.start(stream, 1))) return rc;
             hipLaunchKernelGGL((text_top_pass_kernel<512>), dim3(g.tiles), dim3(512), 0, stream, t);

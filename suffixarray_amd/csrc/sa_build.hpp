@@ -28,6 +28,7 @@
 
 #include "common.hpp"
 #include "radix_narrow.hpp"
+#include "radix_narrow48.hpp"
 #include "round_sort.hpp"
 #include "group_finish.hpp"
 
@@ -938,6 +939,7 @@ struct Builder {
     DevBuf apos0, apos1, apos2, aidx, gid, rkeys0, rkeys1, ridx0, ridx1, lf, tile_last, carry;
     RadixWorkspace radix;
     NarrowWorkspace narrow;
+    bool narrow48 = true;             // SA_HIP_NARROW48: 10-byte records for initial keys of 41..56 bits (radix_narrow48.hpp)
     u32* sa = nullptr;        // points into vals0/vals1 after a build (or into sa_own after load)
     DevBuf sa_own;
     u64 n = 0;
@@ -997,8 +999,16 @@ struct Builder {
     // Characters in the initial key.  Enough that, for an i.i.d. text with this byte
     // distribution, about 2 % of the suffixes still share their key (collision probability
     // per character c2 = sum p_i^2), then rounded up to fill whole 8-bit sort passes.
+    // the 10-byte-record plan can be taken at all (the key length decides later whether it is)
+    bool narrow48_possible(int b) const {
+        return narrow_sort && narrow48 && fuse_hist && text_top_pass && radix.block == 512 && b <= 8 && n >= (1u << 22) &&
+               n / (512u * SEG48_LAST_ITEMS) + RADIX + 1 <= radix.max_tiles;
+    }
     int choose_initial_chars(int b, u32 L) const {
-        const int kmax = 64 / b;
+        // the longest key: 64 bits as 12-byte records, or -- where the 10-byte-record plan applies -- 56 bits (for word / name
+        // texts one character less in the key costs less than 4 bytes per record and pass: config 5 70.1 vs 70.2 ms at
+        // 11 / 12 characters on 12-byte records)
+        const int kmax = (narrow48_possible(b) && 56 / b >= 6) ? 56 / b : 64 / b;
         int k = kmax;
         if (initial_chars_override > 0) {
             k = initial_chars_override < kmax ? initial_chars_override : kmax;
@@ -1040,6 +1050,7 @@ struct Builder {
         if (const char* e = diag_env("SA_HIP_FUSE_HIST")) fuse_hist = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_FUSE_DIR")) fuse_directory = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_NARROW")) narrow_sort = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_NARROW48")) narrow48 = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_TEXT_PASS")) text_top_pass = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_WIDE_TEXT_PASS")) wide_text_pass = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_NARROW_K")) narrow_k = atoi(e) != 0;
@@ -1491,6 +1502,8 @@ struct Builder {
         const int begin_bit = 64 - b * k0;
         if ((rc = make_plan(radix, n32, begin_bit, 64, pl))) return rc;
         const bool narrow_path = narrow_sort && fuse_hist && narrow_sort_applies(radix, n, begin_bit);
+        const bool narrow48_path = !narrow_path && narrow48_possible(b) && narrow48_applies(radix, n, begin_bit, b, k0);
+        stats.narrow48 = narrow48_path ? 1u : 0u;
         if (fuse_hist) { if ((rc = radix_prepare(radix, stream))) return rc; }
         // the narrow sort starts with the TOP digit, the plain LSD sort with the lowest one; when the top-digit
         // pass reads the text itself, key generation shrinks to the histogram of that digit
@@ -1499,10 +1512,10 @@ struct Builder {
         // (a narrow sort fed from a u64 key array -- no text pass -- needs the wide buffers for that array)
         if ((rc = ensure_key_buffers(n, narrow_path && text_pass && narrow_k && fuse_directory))) return rc;
         // the plain 12-byte-record sort can take its pass 0 from the text too (no key array written and read back)
-        const bool wide_text = !narrow_path && wide_text_pass && fuse_hist && radix.block == 512 && text_pass_applies(b, k0) &&
+        const bool wide_text = !narrow_path && !narrow48_path && wide_text_pass && fuse_hist && radix.block == 512 && text_pass_applies(b, k0) &&
                                pl.npasses > 1 && n >= (1u << 16);
-        stats.text_top_pass = (text_pass || wide_text) ? 1u : 0u;
-        if (text_pass) {
+        stats.text_top_pass = (text_pass || wide_text || narrow48_path) ? 1u : 0u;
+        if (text_pass || narrow48_path) {
             if ((rc = narrow_text_histogram(radix, narrow, stream, text.as<u8>(), map, n32, b))) return rc;
         } else if (wide_text) {
             if ((rc = wide_text_histogram(radix, narrow, stream, text.as<u8>(), map, n32, b, k0))) return rc;
@@ -1521,6 +1534,12 @@ struct Builder {
             src.text = text.as<u8>(); src.b = b; src.k0 = k0;
             if ((rc = radix_sort_narrow(radix, narrow, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(),
                                         n32, begin_bit, &kres, &vres, text_pass ? &src : nullptr, keep_narrow, sa64_out))) return rc;
+            if (sa64_out) stats.widen_fused = 1;
+        } else if (narrow48_path) {
+            TextSource src;
+            src.text = text.as<u8>(); src.b = b; src.k0 = k0;
+            if ((rc = radix_sort_narrow48(radix, narrow, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(),
+                                          n32, begin_bit, &kres, &vres, src, sa64_out))) return rc;
             if (sa64_out) stats.widen_fused = 1;
         } else {
             WideTextCtx wctx{text.as<u8>(), narrow.map_dev, n, b, k0};

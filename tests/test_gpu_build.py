@@ -154,6 +154,53 @@ def test_narrow_record_sort_matches_plain_sort(gpu, oracle, monkeypatch):
         assert np.array_equal(idx.sa_u32(), oracle.sais(t).astype(np.uint32))
 
 
+def test_narrow48_record_sort_matches_wide_sort(gpu, oracle, monkeypatch):
+    """Initial keys of 41..56 bits are sorted as 10-byte records (radix_narrow48.hpp: top digit from the text, the 48-bit
+    remainder as u32 + u16, two passes ranked by the u16 part, three or four by the u32 part, u64 keys rebuilt by the last
+    pass).  Same suffix array as the 12-byte-record sort (SA_HIP_NARROW48=0), verified on the device, equal to the oracle's;
+    forced key lengths cover every split of the remainder (33..48 bits: last passes of 1..8 bits, three and four upper
+    passes); a skewed alphabet (one huge bucket), two symbols, DNA-like text, word and name text with the pilot's key;
+    truncated builds keep ties in text order; queries over the rebuilt key array answer like the oracle."""
+    from suffixarray_amd import synth
+    rng = np.random.default_rng(12)
+    words = synth.d2_words(6_000_000)
+    d1 = synth.d1_uniform27(4_700_000)
+    dna = rng.choice(np.frombuffer(b"acgt", np.uint8), 5_000_000)
+    skew = rng.choice(np.array([97, 98, 99, 100, 122], dtype=np.uint8), 6_000_000, p=[0.9, 0.04, 0.03, 0.02, 0.01])
+    two = rng.choice(np.array([97, 122], dtype=np.uint8), 5_000_000)
+    sym60 = rng.integers(60, 120, 4_500_000).astype(np.uint8)
+    runs = [("words", words, 0, 0), ("words_L20", words, 0, 20), ("words_k9", words, 9, 0), ("words_k10", words, 10, 0),
+            ("d1_k9", d1, 9, 0), ("d1_k11", d1, 11, 0), ("dna", dna, 0, 0), ("dna_k14", dna, 14, 0), ("dna_k16", dna, 16, 0),
+            ("skew_k17", skew, 17, 0), ("two_k24", two, 24, 0), ("two_k21_L30", two, 21, 30), ("sym60_k8", sym60, 8, 0), ("sym60_k9", sym60, 9, 7)]
+    for name, t, k0, L in runs:
+        if k0:
+            monkeypatch.setenv("SA_HIP_INITIAL_CHARS", str(k0))
+        else:
+            monkeypatch.delenv("SA_HIP_INITIAL_CHARS", raising=False)
+        got, stats = {}, {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SA_HIP_NARROW48", mode)
+            with gpu.DeviceIndex(t.size, 0) as idx:
+                idx.build(t, L)
+                st = stats[mode] = idx.build_stats()
+                assert bool(st["narrow48"]) == (mode == "1"), (name, st)
+                assert idx.verify() == 0, (name, mode, st)
+                got[mode] = idx.sa_u32().copy()
+                if mode == "1" and name in ("words", "words_L20", "dna", "two_k24"):
+                    pats = cases.query_patterns(t, 1500, rng)
+                    exp = oracle.query_batch(t, got[mode], L if L else 0xFFFFFFFF, pats)
+                    assert np.array_equal(idx.query_batch(pats), exp), name
+        assert np.array_equal(got["1"], got["0"]), (name, stats)
+        bits = stats["1"]["initial_chars"] * stats["1"]["bits_per_symbol"]
+        assert 40 < bits <= 56, (name, stats["1"])
+        if name in ("words", "dna", "d1_k11"):
+            assert np.array_equal(got["1"], oracle.sais(t).astype(np.uint32)), name
+        if L:
+            assert np.array_equal(got["1"], oracle.truncated_sa(t, L)), name
+    monkeypatch.delenv("SA_HIP_INITIAL_CHARS", raising=False)
+    monkeypatch.delenv("SA_HIP_NARROW48", raising=False)
+
+
 def test_rounds_sorted_in_lds_match_global_sort(gpu, oracle, monkeypatch):
     """Refinement rounds are sorted group-wise in LDS (round_sort.hpp: tiles of whole groups, 12-bit local group ids,
     packed and unpacked record form, groups too large for a tile through the global sort as a compact list).  Same
@@ -307,6 +354,9 @@ def test_build_device64_is_the_libsais64_layout(gpu, oracle, monkeypatch):
     run = synth.d2_words(5_000_000).copy()
     run[2_000_000:2_060_000] = ord("q")
     runs += [("blocks", blocks, 0, {"SA_HIP_PILOT": "0"}, True), ("run", run, 0, {"SA_HIP_PILOT": "0"}, True)]
+    # the 10-byte-record plan (pilot's key: 11 characters) writes the int64 copy in its last pass too
+    runs += [("words48", synth.d2_words(5_000_000), 0, {}, True), ("words48_L20", synth.d2_words(5_000_000), 20, {}, True),
+             ("blocks48", blocks, 0, {}, True)]
     for name, t, L, env, fused in runs:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -318,8 +368,9 @@ def test_build_device64_is_the_libsais64_layout(gpu, oracle, monkeypatch):
             idx.sync()
             st = idx.build_stats()
             assert bool(st["widen_fused"]) == fused, (name, st)
-            if name in ("blocks", "run"):
+            if name in ("blocks", "run", "blocks48"):
                 assert st["doubling_rounds"] > 0, (name, st)
+            assert bool(st["narrow48"]) == name.endswith(("48", "48_L20")), (name, st)
             assert idx.verify() == 0, name
             got = out.cpu().numpy()
             assert np.array_equal(got[:t.size], idx.sa_u32().astype(np.int64)), name
@@ -342,6 +393,7 @@ def test_wide_sort_from_the_text_matches_key_array(gpu, oracle, monkeypatch):
     words = synth.d2_words(5_000_003)
     dna = (rng.integers(0, 4, 3_000_000).astype(np.uint8) + 97)
     sym200 = rng.choice(np.arange(20, 220, dtype=np.uint8), 2_500_000)
+    monkeypatch.setenv("SA_HIP_NARROW48", "0")   # this test is about the 12-byte-record plan (the 10-byte plan has its own above)
     runs = [("words", words, 0, {}), ("words_L30", words, 30, {}), ("words_k9", words, 0, {"SA_HIP_INITIAL_CHARS": "9"}),
             ("words_k10", words, 0, {"SA_HIP_INITIAL_CHARS": "10"}), ("words_k11", words, 0, {"SA_HIP_INITIAL_CHARS": "11"}),
             ("d1_plain", synth.d1_uniform27(4_600_000), 0, {"SA_HIP_NARROW": "0"}), ("d1_plain_k12", synth.d1_uniform27(300_000), 0, {"SA_HIP_INITIAL_CHARS": "12"}),
@@ -371,3 +423,4 @@ def test_wide_sort_from_the_text_matches_key_array(gpu, oracle, monkeypatch):
         exp = oracle.truncated_sa(t, L) if L else oracle.sais(t).astype(np.uint32)
         assert np.array_equal(got["1"], exp), name
     monkeypatch.delenv("SA_HIP_WIDE_TEXT_PASS", raising=False)
+    monkeypatch.delenv("SA_HIP_NARROW48", raising=False)
