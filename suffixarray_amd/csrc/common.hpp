@@ -49,6 +49,7 @@ inline int bits_for(u64 count) {
     return b;
 }
 
+#if defined(__HIPCC__)   // device helpers: absent when a host compiler builds the host-only headers (tools/host_sanitize.cpp)
 __device__ __forceinline__ u64 lanemask_lt() {
     return (1ull << (threadIdx.x & 63)) - 1ull;
 }
@@ -64,6 +65,7 @@ __device__ __forceinline__ void sync_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
 }
+#endif
 
 // Diagnostic switches (SA_HIP_*): read from the environment ONLY when SA_HIP_DIAG=1 is set as well -- the behaviour of a
 // production process does not depend on stray variables of its caller; the tests and tools/ set SA_HIP_DIAG=1 to run

@@ -14,6 +14,8 @@
 #include "records.hpp"
 #include "host_io.hpp"
 #include "rows_device.hpp"
+#include "host_index.hpp"
+#include <memory>
 #include <chrono>
 
 using namespace sa;
@@ -43,6 +45,7 @@ struct sa_hip_index {
     std::vector<u64> row_starts;   // sa_hip_index_set_rows: offset of every row (document, CSV field) in the indexed text
     DevBuf rows_dev;               // the same table in HBM (rows_device.hpp)
     DevBuf r_rows, r_counts;       // results of the rows kernel (batched form)
+    std::unique_ptr<HostIndex> host;   // set: the opt-in no-GPU path of config 1 (host_index.hpp); nothing below touches HIP then
     bool receiving = false;        // sa_hip_index_replica_reserve .. _commit: the buffers are being filled by the caller
     sa_hip_replica_layout pending{};
 };
@@ -156,6 +159,17 @@ int sa_hip_index_create(sa_hip_index** out, uint64_t n_max, int device) {
     *out = nullptr;
     if (n_max > 0xFFFFFFFEull) return fail(SA_HIP_EINVAL, "sa_hip_index_create: n_max exceeds 2^32 - 2");
     int cnt = sa_hip_device_count();
+    if (cnt <= 0 && host_path_allowed()) {
+        // no usable HIP device and the caller opted in (SA_HIP_ALLOW_HOST=1): the small host implementation of config 1
+        if (n_max > HOST_MAX_N) return fail(SA_HIP_EINVAL, "sa_hip_index_create: the host path (no HIP device) holds at most 2^24 bytes");
+        sa_hip_index* h = new (std::nothrow) sa_hip_index();
+        if (!h) return fail(SA_HIP_ENOMEM, "sa_hip_index_create: host allocation");
+        try { h->host.reset(new HostIndex()); } catch (const std::bad_alloc&) { delete h; return fail(SA_HIP_ENOMEM, "sa_hip_index_create: host allocation"); }
+        h->host->n_max = n_max;
+        h->device = -1;
+        *out = h;
+        return 0;
+    }
     if (cnt < 0) return cnt;
     if (device < 0 || device >= cnt) return fail(SA_HIP_EHIP, "sa_hip_index_create: no such HIP device");
     int rc = set_device(device);
@@ -179,6 +193,7 @@ int sa_hip_index_create(sa_hip_index** out, uint64_t n_max, int device) {
 
 void sa_hip_index_destroy(sa_hip_index* idx) {
     if (!idx) return;
+    if (idx->host) { delete idx; return; }
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     idx->b.destroy();
@@ -196,6 +211,14 @@ void sa_hip_index_destroy(sa_hip_index* idx) {
 int sa_hip_index_build(sa_hip_index* idx, const uint8_t* T_host, uint64_t n, uint32_t max_suffix_length) {
     if (!idx || (!T_host && n)) return fail(SA_HIP_EINVAL, "sa_hip_index_build: NULL argument");
     std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->host) {
+        HostIndex& h = *idx->host;
+        if (n > h.n_max) return fail(SA_HIP_EINVAL, "sa_hip_index_build: n exceeds the index capacity");
+        try { h.set_text(T_host, n); h.build(max_suffix_length); }
+        catch (const std::bad_alloc&) { return fail(SA_HIP_ENOMEM, "sa_hip_index_build: out of host memory"); }
+        idx->has_index = true;
+        return 0;
+    }
     int rc = set_device(idx->device);
     if (rc) return rc;
     if (n > idx->b.n_max) return fail(SA_HIP_EINVAL, "sa_hip_index_build: n exceeds the index capacity");
@@ -210,6 +233,7 @@ int sa_hip_index_build(sa_hip_index* idx, const uint8_t* T_host, uint64_t n, uin
 int sa_hip_index_build_device(sa_hip_index* idx, const void* T_dev, uint64_t n, uint32_t max_suffix_length) {
     if (!idx || (!T_dev && n)) return fail(SA_HIP_EINVAL, "sa_hip_index_build_device: NULL argument");
     std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->host) return fail(SA_HIP_EHIP, "sa_hip_index_build_device: the host path (no HIP device) has no device buffers");
     int rc = set_device(idx->device);
     if (rc) return rc;
     if (n > idx->b.n_max) return fail(SA_HIP_EINVAL, "sa_hip_index_build_device: n exceeds the index capacity");
@@ -225,6 +249,7 @@ int sa_hip_index_build_device(sa_hip_index* idx, const void* T_dev, uint64_t n, 
 int sa_hip_index_build_device64(sa_hip_index* idx, const void* T_dev, uint64_t n, uint32_t max_suffix_length, void* sa64_dev) {
     if (!idx || (!T_dev && n) || (!sa64_dev && n)) return fail(SA_HIP_EINVAL, "sa_hip_index_build_device64: NULL argument");
     std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->host) return fail(SA_HIP_EHIP, "sa_hip_index_build_device64: the host path (no HIP device) has no device buffers");
     int rc = set_device(idx->device);
     if (rc) return rc;
     if (n > idx->b.n_max) return fail(SA_HIP_EINVAL, "sa_hip_index_build_device64: n exceeds the index capacity");
@@ -239,6 +264,18 @@ int sa_hip_index_build_device64(sa_hip_index* idx, const void* T_dev, uint64_t n
 
 static int load_common(sa_hip_index* idx, const void* T, const void* SA, uint64_t n, uint32_t L, hipMemcpyKind kind) {
     std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->host) {
+        if (kind != hipMemcpyHostToDevice) return fail(SA_HIP_EHIP, "sa_hip_index_load_device: the host path (no HIP device) has no device buffers");
+        HostIndex& h = *idx->host;
+        if (n > h.n_max) return fail(SA_HIP_EINVAL, "sa_hip_index_load: n exceeds the index capacity");
+        const u32* s32 = static_cast<const u32*>(SA);
+        for (u64 i = 0; i < n; ++i) if (s32[i] >= n) return fail(SA_HIP_EINVAL, "sa_hip_index_load: suffix array holds entries >= n");
+        try { h.set_text(static_cast<const u8*>(T), n); h.sa.assign(s32, s32 + n); }
+        catch (const std::bad_alloc&) { return fail(SA_HIP_ENOMEM, "sa_hip_index_load: out of host memory"); }
+        h.L = L; h.ready = true;
+        idx->has_index = true;
+        return 0;
+    }
     int rc = set_device(idx->device);
     if (rc) return rc;
     if (n > idx->b.n_max) return fail(SA_HIP_EINVAL, "sa_hip_index_load: n exceeds the index capacity");
@@ -304,6 +341,7 @@ static void fill_layout(const sa_hip_index* idx, sa_hip_replica_layout* out) {
 int sa_hip_index_replica_layout(sa_hip_index* idx, sa_hip_replica_layout* out) {
     if (!idx || !out) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_layout: NULL argument");
     std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->host) return fail(SA_HIP_EHIP, "sa_hip_index_replica_layout: the host path (no HIP device) has no device buffers");
     if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_layout: no index");
     fill_layout(idx, out);
     return 0;
@@ -322,6 +360,7 @@ static void fill_buffers(const sa_hip_index* idx, const sa_hip_replica_layout& l
 int sa_hip_index_replica_buffers(sa_hip_index* idx, sa_hip_replica_buffers* out) {
     if (!idx || !out) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_buffers: NULL argument");
     std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->host) return fail(SA_HIP_EHIP, "sa_hip_index_replica_buffers: the host path (no HIP device) has no device buffers");
     if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_buffers: no index");
     int rc = set_device(idx->device);
     if (rc) return rc;
@@ -335,6 +374,7 @@ int sa_hip_index_replica_buffers(sa_hip_index* idx, sa_hip_replica_buffers* out)
 int sa_hip_index_replica_reserve(sa_hip_index* idx, const sa_hip_replica_layout* l, sa_hip_replica_buffers* out) {
     if (!idx || !l || !out) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_reserve: NULL argument");
     std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->host) return fail(SA_HIP_EHIP, "sa_hip_index_replica_reserve: the host path (no HIP device) has no device buffers");
     if (l->n > idx->b.n_max) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_reserve: n exceeds the index capacity");
     if (l->key_bytes != 0 && l->key_bytes != 4 && l->key_bytes != 8) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_reserve: bad key width");
     if (l->key_bytes && (l->dir_bits < 8 || l->dir_bits > 28 || l->dir_entries != (1ull << l->dir_bits) + 1 || l->bits_per_symbol < 1 ||
@@ -368,6 +408,7 @@ int sa_hip_index_replica_reserve(sa_hip_index* idx, const sa_hip_replica_layout*
 int sa_hip_index_replica_commit(sa_hip_index* idx) {
     if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_commit: NULL index");
     std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->host) return fail(SA_HIP_EHIP, "sa_hip_index_replica_commit: the host path (no HIP device) has no device buffers");
     if (!idx->receiving) return fail(SA_HIP_EINVAL, "sa_hip_index_replica_commit: nothing reserved");
     int rc = set_device(idx->device);
     if (rc) return rc;
@@ -401,14 +442,15 @@ int sa_hip_index_replica_commit(sa_hip_index* idx) {
     return 0;
 }
 
-uint64_t sa_hip_index_n(const sa_hip_index* idx) { return idx ? idx->b.n : 0; }
-uint32_t sa_hip_index_max_suffix_length(const sa_hip_index* idx) { return idx ? idx->b.max_suffix_length : 0; }
-const void* sa_hip_index_text_dev(const sa_hip_index* idx) { return idx ? idx->b.text.p : nullptr; }
-const void* sa_hip_index_sa_dev(const sa_hip_index* idx) { return (idx && idx->has_index) ? idx->b.sa : nullptr; }
+uint64_t sa_hip_index_n(const sa_hip_index* idx) { return idx ? (idx->host ? idx->host->n : idx->b.n) : 0; }
+uint32_t sa_hip_index_max_suffix_length(const sa_hip_index* idx) { return idx ? (idx->host ? idx->host->L : idx->b.max_suffix_length) : 0; }
+const void* sa_hip_index_text_dev(const sa_hip_index* idx) { return (idx && !idx->host) ? idx->b.text.p : nullptr; }
+const void* sa_hip_index_sa_dev(const sa_hip_index* idx) { return (idx && idx->has_index && !idx->host) ? idx->b.sa : nullptr; }
 void* sa_hip_index_stream(const sa_hip_index* idx) { return idx ? (void*)idx->stream : nullptr; }
 
 int sa_hip_index_sync(sa_hip_index* idx) {
     if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_sync: NULL index");
+    if (idx->host) return 0;
     int rc = set_device(idx->device);
     if (rc) return rc;
     SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
@@ -419,6 +461,7 @@ int sa_hip_index_verify(sa_hip_index* idx, uint64_t* violations) {
     if (!idx || !violations) return fail(SA_HIP_EINVAL, "sa_hip_index_verify: NULL argument");
     std::lock_guard<std::mutex> g(idx->mu);   // has_index / n are only read under the lock (a concurrent build rewrites them)
     if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_verify: no index");
+    if (idx->host) { *violations = idx->host->verify(); return 0; }
     int rc = set_device(idx->device);
     if (rc) return rc;
     return idx->b.verify(violations);
@@ -428,7 +471,8 @@ int sa_hip_index_get_sa_u32(sa_hip_index* idx, uint32_t* out_host) {
     if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_u32: NULL index");
     std::lock_guard<std::mutex> g(idx->mu);
     if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_u32: no index");
-    if (!out_host && idx->b.n) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_u32: NULL output");
+    if (!out_host && sa_hip_index_n(idx)) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_u32: NULL output");
+    if (idx->host) { if (idx->host->n) memcpy(out_host, idx->host->sa.data(), (size_t)idx->host->n * 4); return 0; }
     int rc = set_device(idx->device);
     if (rc) return rc;
     if (idx->b.n) SA_HIP_CHECK(hipMemcpyAsync(out_host, idx->b.sa, (size_t)idx->b.n * 4, hipMemcpyDeviceToHost, idx->stream));
@@ -440,7 +484,8 @@ int sa_hip_index_get_sa_i64(sa_hip_index* idx, int64_t* out_host) {
     if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_i64: NULL index");
     std::lock_guard<std::mutex> g(idx->mu);
     if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_i64: no index");
-    if (!out_host && idx->b.n) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_i64: NULL output");
+    if (!out_host && sa_hip_index_n(idx)) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_i64: NULL output");
+    if (idx->host) { for (u64 i = 0; i < idx->host->n; ++i) out_host[i] = (int64_t)idx->host->sa[i]; return 0; }
     int rc = set_device(idx->device);
     if (rc) return rc;
     const u64 n = idx->b.n;
@@ -462,6 +507,7 @@ int sa_hip_index_get_sa_i64(sa_hip_index* idx, int64_t* out_host) {
 int sa_hip_index_widen_device(sa_hip_index* idx, void* out_dev) {
     if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_widen_device: NULL index");
     std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->host) return fail(SA_HIP_EHIP, "sa_hip_index_widen_device: the host path (no HIP device) has no device buffers");
     if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_widen_device: no index");
     const u64 n = idx->b.n;
     if (!out_dev && n) return fail(SA_HIP_EINVAL, "sa_hip_index_widen_device: NULL output");
@@ -479,8 +525,10 @@ int sa_hip_index_widen_device(sa_hip_index* idx, void* out_dev) {
 // (idx->mu held)
 static int get_sa_range_locked(sa_hip_index* idx, uint64_t first, uint64_t count, uint32_t* out_host) {
     if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: no index");
-    if (first > idx->b.n || count > idx->b.n - first) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: out of range");
+    const u64 n_idx = idx->host ? idx->host->n : idx->b.n;
+    if (first > n_idx || count > n_idx - first) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: out of range");
     if (!out_host && count) return fail(SA_HIP_EINVAL, "sa_hip_index_get_sa_range: NULL output");
+    if (idx->host) { if (count) memcpy(out_host, idx->host->sa.data() + first, (size_t)count * 4); return 0; }
     int rc = set_device(idx->device);
     if (rc) return rc;
     if (count) SA_HIP_CHECK(hipMemcpyAsync(out_host, idx->b.sa + first, (size_t)count * 4, hipMemcpyDeviceToHost, idx->stream));
@@ -496,7 +544,7 @@ int sa_hip_index_get_sa_range(sa_hip_index* idx, uint64_t first, uint64_t count,
 
 int sa_hip_index_get_freq(sa_hip_index* idx, uint64_t* freq256) {
     if (!idx || !freq256) return fail(SA_HIP_EINVAL, "sa_hip_index_get_freq: NULL argument");
-    memcpy(freq256, idx->b.freq, sizeof idx->b.freq);
+    memcpy(freq256, idx->host ? idx->host->freq : idx->b.freq, sizeof idx->b.freq);
     return 0;
 }
 
@@ -509,6 +557,10 @@ int sa_hip_query_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_
     if (!offsets || !out) return fail(SA_HIP_EINVAL, "sa_hip_query_batch: NULL argument");
     const u64 total = offsets[Q];
     if (!patterns && total) return fail(SA_HIP_EINVAL, "sa_hip_query_batch: NULL patterns");
+    if (idx->host) {
+        for (u64 i = 0; i < Q; ++i) out[i] = idx->host->query(patterns + offsets[i], offsets[i + 1] - offsets[i]);
+        return 0;
+    }
     int rc = set_device(idx->device);
     if (rc) return rc;
     if ((rc = idx->q_pat.ensure((size_t)total + 64))) return rc;
@@ -530,6 +582,16 @@ static int query_hits_locked(sa_hip_index* idx, const uint8_t* pattern, uint64_t
     if (len > QH_BYTES - 64 - QH_OFF_PATTERN) return fail(SA_HIP_EINVAL, "sa_hip_index_query_hits: pattern longer than 47 KB");
     if (max_hits > QH_MAX_HITS) max_hits = QH_MAX_HITS;
     if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_query_hits: no index");
+    if (idx->host) {
+        const HostIndex& h = *idx->host;
+        *range = h.query(pattern, len);
+        u32 count = 0;
+        if (range->first != 0xFFFFFFFFu && (u32)(range->second - range->first + 1u) != 0u) count = range->second - range->first + 1u;
+        if (count > max_hits) count = max_hits;
+        for (u32 i = 0; i < count; ++i) hits[i] = h.sa[(u64)range->first + i];
+        *nhits = count;
+        return 0;
+    }
     int rc = set_device(idx->device);
     if (rc) return rc;
     if (!idx->qh_host) {
@@ -566,6 +628,7 @@ int sa_hip_query_batch_device(sa_hip_index* idx, const void* patterns_dev, const
                               void* out_dev) {
     if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_query_batch_device: NULL index");
     std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->host) return fail(SA_HIP_EHIP, "sa_hip_query_batch_device: the host path (no HIP device) has no device buffers");
     if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_query_batch_device: no index");
     if (Q == 0) return 0;
     if (!patterns_dev || !offsets_dev || !out_dev) return fail(SA_HIP_EINVAL, "sa_hip_query_batch_device: NULL argument");
@@ -577,6 +640,7 @@ int sa_hip_query_batch_device(sa_hip_index* idx, const void* patterns_dev, const
 int sa_hip_query_batch_device_fixed(sa_hip_index* idx, const void* patterns_dev, uint64_t pattern_len, uint64_t Q, void* out_dev) {
     if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_query_batch_device_fixed: NULL index");
     std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->host) return fail(SA_HIP_EHIP, "sa_hip_query_batch_device_fixed: the host path (no HIP device) has no device buffers");
     if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_query_batch_device_fixed: no index");
     if (Q == 0) return 0;
     if ((!patterns_dev && pattern_len) || !out_dev) return fail(SA_HIP_EINVAL, "sa_hip_query_batch_device_fixed: NULL argument");
@@ -589,6 +653,7 @@ int sa_hip_index_build_stats(const sa_hip_index* idx_c, sa_hip_build_stats* out)
     sa_hip_index* idx = const_cast<sa_hip_index*>(idx_c);
     if (!idx || !out) return fail(SA_HIP_EINVAL, "sa_hip_index_build_stats: NULL argument");
     std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->host) { memset(out, 0, sizeof *out); out->n = idx->host->n; return 0; }
     if (idx->widen_ms < 0.0) {
         int rc = set_device(idx->device);
         if (rc) return rc;
@@ -606,6 +671,7 @@ int sa_hip_index_query_stats(const sa_hip_index* idx_c, sa_hip_query_stats* out)
     sa_hip_index* idx = const_cast<sa_hip_index*>(idx_c);
     if (!idx || !out) return fail(SA_HIP_EINVAL, "sa_hip_index_query_stats: NULL argument");
     std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->host) { memset(out, 0, sizeof *out); return 0; }
     int rc = set_device(idx->device);
     if (rc) return rc;
     if ((rc = resolve_query_events(idx, sa_hip_index::QRING))) return rc;
@@ -628,6 +694,7 @@ int sa_hip_index_set_rows(sa_hip_index* idx, const uint64_t* row_text_starts, ui
     std::lock_guard<std::mutex> g(idx->mu);
     try { idx->row_starts.assign(row_text_starts, row_text_starts + num_rows); }
     catch (const std::bad_alloc&) { return fail(SA_HIP_ENOMEM, "sa_hip_index_set_rows: out of host memory"); }
+    if (idx->host) return 0;
     // ... and in HBM for the rows kernel
     int rc = set_device(idx->device);
     if (rc) return rc;
@@ -641,7 +708,8 @@ int sa_hip_index_get_text(sa_hip_index* idx, uint8_t* out_host) {
     if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_get_text: NULL index");
     std::lock_guard<std::mutex> g(idx->mu);
     if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_get_text: no index");
-    if (!out_host && idx->b.n) return fail(SA_HIP_EINVAL, "sa_hip_index_get_text: NULL output");
+    if (!out_host && sa_hip_index_n(idx)) return fail(SA_HIP_EINVAL, "sa_hip_index_get_text: NULL output");
+    if (idx->host) { if (idx->host->n) memcpy(out_host, idx->host->text.data(), (size_t)idx->host->n); return 0; }
     int rc = set_device(idx->device);
     if (rc) return rc;
     if (idx->b.n) SA_HIP_CHECK(hipMemcpyAsync(out_host, idx->b.text.p, (size_t)idx->b.n, hipMemcpyDeviceToHost, idx->stream));
@@ -701,7 +769,7 @@ int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t 
     if (k && idx->row_starts.empty()) return fail(SA_HIP_EINVAL, "sa_hip_index_query_rows: no row table (sa_hip_index_set_rows)");
     // more rows than the table holds cannot come back: k = 10^9 ("all") must not size anything
     if ((u64)k > idx->row_starts.size()) k = (u32)idx->row_starts.size();
-    if (k && k <= ROWS_K_MAX && !host_rows_forced()) return query_rows_device_locked(idx, pattern, len, k, row_ids, num_rows, range);
+    if (k && k <= ROWS_K_MAX && !host_rows_forced() && !idx->host) return query_rows_device_locked(idx, pattern, len, k, row_ids, num_rows, range);
     const u32 cap = k ? std::min<u32>(std::max<u32>(4u * k, 1024u), QH_MAX_HITS) : 0u;
     try {
         std::vector<u32> first(cap ? cap : 1);
@@ -732,6 +800,22 @@ int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, co
     if (k && idx->row_starts.empty()) return fail(SA_HIP_EINVAL, "sa_hip_index_query_rows_batch: no row table (sa_hip_index_set_rows)");
     if ((u64)k > idx->row_starts.size()) k = (u32)idx->row_starts.size();
     for (u64 i = 0; i < Q; ++i) counts[i] = 0;
+    if (idx->host) {
+        try {
+            std::vector<u64> rows;
+            for (u64 q = 0; q < Q; ++q) {
+                const sa_hip_pair_u32 rg = idx->host->query(patterns + offsets[q], offsets[q + 1] - offsets[q]);
+                if (ranges) ranges[q] = rg;
+                if (!k) continue;
+                int rc = distinct_rows(idx->row_starts, rg, k, nullptr, 0,
+                                       [&](u64 pos, u64 count, u32* out) { return get_sa_range_locked(idx, pos, count, out); }, rows);
+                if (rc) return rc;
+                for (size_t i = 0; i < rows.size(); ++i) row_ids[q * k_in + i] = rows[i];
+                counts[q] = (u32)rows.size();
+            }
+        } catch (const std::bad_alloc&) { return fail(SA_HIP_ENOMEM, "sa_hip_index_query_rows_batch: out of host memory"); }
+        return 0;
+    }
     int rc = set_device(idx->device);
     if (rc) return rc;
     // ONE search launch for all the ranges
@@ -789,7 +873,7 @@ int sa_hip_index_rows_for_range(sa_hip_index* idx, sa_hip_pair_u32 range, uint32
     std::lock_guard<std::mutex> g(idx->mu);
     if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: no index");
     if (range.first != 0xFFFFFFFFu && (u32)(range.second - range.first + 1u) != 0u &&
-        ((u64)range.second >= idx->b.n || range.first > range.second)) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: range outside the suffix array");
+        ((u64)range.second >= (idx->host ? idx->host->n : idx->b.n) || range.first > range.second)) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: range outside the suffix array");
     if (k && idx->row_starts.empty()) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: no row table (sa_hip_index_set_rows)");
     if ((u64)k > idx->row_starts.size()) k = (u32)idx->row_starts.size();
     try {
@@ -1027,6 +1111,17 @@ int oneshot_build(const uint8_t* T, uint64_t n, uint32_t L, OUT* out, FREQ* freq
     OneShot& g = g_oneshot;
     std::lock_guard<std::mutex> lock(g.mu);
     const auto t_all = std::chrono::steady_clock::now();
+    if (!g.idx && host_path_allowed() && sa_hip_device_count() <= 0) {   // opt-in no-GPU path (host_index.hpp)
+        if (n > HOST_MAX_N) return fail(SA_HIP_EINVAL, "the host path (no HIP device) holds at most 2^24 bytes");
+        try {
+            HostIndex h;
+            h.set_text(T, n);
+            h.build(L);
+            for (u64 i = 0; i < n; ++i) out[i] = (OUT)h.sa[i];
+            if (freq) for (int c = 0; c < 256; ++c) freq[c] = (FREQ)h.freq[c];
+        } catch (const std::bad_alloc&) { return fail(SA_HIP_ENOMEM, "out of host memory"); }
+        return 0;
+    }
     sa_hip_call_breakdown bd{};
     bd.n = n;
     int rc = 0;

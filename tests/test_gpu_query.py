@@ -387,7 +387,7 @@ def test_device_rows_equal_host_rows(gpu, monkeypatch):
         col = extract_column(path, "company_name")
     text = np.frombuffer(col.text, dtype=np.uint8)
     names = bytes(col.text).split(b"\n")[:-1]
-    starts = np.asarray(col.row_text_starts, dtype=np.uint64)
+    starts = np.asarray(col.text_row_starts, dtype=np.uint64)
     rng = np.random.default_rng(6)
     pats = [names[i] for i in rng.integers(0, len(names), 150)] + [names[i][2:6] for i in rng.integers(0, len(names), 60)]
     pats += [b"inc", b" ", b"a", b"llc", b"zzqqzz", b"e", names[0], b", inc.", b"\n"]

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import cases
+from conftest import GOLDEN
 from pipeline_model import build_sa_model
 from test_oracle import check_truncated_order
 
@@ -55,6 +56,65 @@ def test_no_gpu_means_loud_failure(capi):
         capi.DeviceIndex(1024, 0)
     with pytest.raises(capi.SaHipError):
         capi.libsais(b"banana")
+
+
+def test_config1_readme_on_the_opt_in_host_path(capi, oracle, monkeypatch, tmp_path):
+    """BASELINE config 1 ("3-doc README example via SuffixArray(documents=...), CPU path, no GPU"): with no HIP device AND
+    SA_HIP_ALLOW_HOST=1 the handle API is served by the library's own small host implementation (csrc/host_index.hpp;
+    never the oracle, which only checks it here).  The README documents give the reference-generated golden ranges; suffix
+    arrays equal the oracle's on small and adversarial texts, full and truncated; record retrieval, the CSV mode and
+    save / load run on it; without the variable nothing changes (test above)."""
+    if capi.lib().sa_hip_device_count() >= 1:
+        pytest.skip("a HIP device is present: the host path is never taken")
+    monkeypatch.setenv("SA_HIP_ALLOW_HOST", "1")
+    from suffixarray_amd import SuffixArray
+    g = np.load(os.path.join(GOLDEN, "golden_readme.npz"), allow_pickle=False)
+    L = int(g["max_suffix_length"][0])
+    docs = ["The quick brown fox jumps over the lazy dog", "I am going to the store to buy some milk",
+            "Uhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhhh"]   # README.md:16-20
+    assert "\n".join(docs).lower().encode() == bytes(g["text"])
+    s = SuffixArray(documents=docs, max_suffix_length=L)
+    pats = [bytes(p) for p in g["patterns"]]
+    got = s.query_ranges(pats)
+    assert np.array_equal(got["first"], g["ranges"]["first"]) and np.array_equal(got["second"], g["ranges"]["second"])
+    assert s.query_records("the quick brown fox") == [docs[0]]
+    assert sorted(s.query_records("THE")) == sorted(docs[:2]) and s.query_records("zzz") == [] and s.query_records("milk", k=1) == [docs[1]]
+    assert s.query_records_batch(["uhh", "", "the"], k=1000)[0] == [docs[2]]
+    idx = s._index
+    assert idx.verify() == 0 and np.array_equal(idx.sa_u32(), oracle.truncated_sa(g["text"], L))
+    s.save(str(tmp_path / "idx"))
+    s2 = SuffixArray.load(str(tmp_path / "idx"))
+    assert s2.query_records("milk") == [docs[1]]
+    s.close(); s2.close()
+    # the handle API against the oracle: full and truncated order, query conventions, the libsais-compatible calls
+    rng = np.random.default_rng(3)
+    texts = cases.small_texts()
+    for name in ("banana", "mississippi", "len1", "aa", "all_a_5000", "ab_3000", "fib", "highbit", "with_nul", "r27_4097", "r2_30000", "repeat_block", "d2_300k"):
+        t = texts[name]
+        sa = oracle.sais(t).astype(np.uint32)
+        with capi.DeviceIndex(t.size, 0) as idx:
+            idx.build(t)
+            assert np.array_equal(idx.sa_u32(), sa), name
+            assert np.array_equal(idx.sa_i64(), sa.astype(np.int64)) and idx.verify() == 0
+            pats = cases.query_patterns(t, 200, rng)
+            assert np.array_equal(idx.query_batch(pats), oracle.query_batch(t, sa, 0xFFFFFFFF, pats)), name
+            for Lt in (1, 2, 3, 5, 8, 13, 32):
+                idx.build(t, Lt)
+                assert np.array_equal(idx.sa_u32(), oracle.truncated_sa(t, Lt)), (name, Lt)
+                assert idx.verify() == 0
+                assert np.array_equal(idx.query_batch(pats[:50]), oracle.query_batch(t, idx.sa_u32(), Lt, pats[:50])), (name, Lt)
+            with pytest.raises(capi.SaHipError):
+                idx.build_device(0, t.size)          # no device buffers on the host path
+        if t.size < 70000:
+            assert np.array_equal(capi.libsais(t), sa.astype(np.int32)) and np.array_equal(capi.libsais64(t), sa.astype(np.int64))
+    with pytest.raises(capi.SaHipError):
+        capi.DeviceIndex((1 << 24) + 1, 0)           # the host path is small on purpose
+    # CSV mode end to end
+    p = tmp_path / "c.csv"
+    p.write_text('id,company_name,country\n1,Netflix,US\n2,"Acme, Inc.",US\n3,netflix studios,US\n')
+    c = SuffixArray(csv_file=str(p), search_column="company_name", max_suffix_length=32)
+    assert [r["id"] for r in c.query_records("netflix")] in (["1", "3"], ["3", "1"]) and c.query_records("acme, inc")[0]["country"] == "US"
+    c.close()
 
 
 def test_synth_d1_matches_definition(capi):
