@@ -117,6 +117,27 @@ def test_config1_readme_on_the_opt_in_host_path(capi, oracle, monkeypatch, tmp_p
     c.close()
 
 
+@pytest.mark.parametrize("flags", ["-fsanitize=address,undefined -fno-sanitize-recover=all", "-fsanitize=thread"])
+def test_host_code_under_sanitizers(tmp_path, flags):
+    """The host-only C++ of the library -- the multi-threaded RFC-4180 column extractor, row copying, hits -> rows, the
+    opt-in host index -- compiled by the host compiler with AddressSanitizer + UBSan, and with ThreadSanitizer, and run
+    (tools/host_sanitize.cpp): sanitizers belong on a CPU build, never on the GPU pool."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("no host compiler / HIP headers")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_sanitize")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", *flags.split(), "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+           "-I" + os.path.join(root, "suffixarray_amd", "csrc"), os.path.join(root, "tools", "host_sanitize.cpp"), "-o", exe, "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    if r.returncode != 0 and ("cannot find" in r.stderr or "unrecognized" in r.stderr):
+        pytest.skip("sanitizer runtime not installed: " + r.stderr[-200:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "clean" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
 def test_synth_d1_matches_definition(capi):
     a = capi.synth_uniform27(1000)
     s = 88172645463325252
