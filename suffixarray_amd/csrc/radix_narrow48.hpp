@@ -16,18 +16,15 @@
 // 55-bit keys (11 characters of 5 bits): 1 + 11 + 2 + 5 * 20 + 22 = 136 bytes per character instead of 1 + 13 + 6 * 24 = 158
 // for the same key length on 12-byte records (181 for the 12 characters the old plan took).  Geometry, look-back chains
 // (one per bucket), per-bucket digit bases and the next pass's histogram are those of radix_narrow.hpp; the rank is
-// computed on whichever array holds the pass's digit, the other array and the values follow as payloads through the
-// same LDS staging buffer, one after the other (no more LDS or registers than the 8-byte-record kernel).  The last pass
+// computed on whichever array holds the pass's digit, both key arrays are staged in LDS side by side at the record's
+// tile-local sorted position (one round for the 6 key bytes), the values follow through the same buffer.  The last pass
 // rebuilds full u64 keys -- the flags pass, the bucket directory and the query kernel see what the 12-byte plan left them.
 #pragma once
 #include "radix_narrow.hpp"
 
 namespace sa {
 
-// records per thread: tiles of 8192.  24 per thread (the 8-byte-record kernel's choice) needs the same four register arrays
-// of 24 plus the u16 conversions: 128 VGPRs with 75 spilled; 16 per thread fit 85 VGPRs = THREE workgroups per CU, which
-// keeps as many bytes in flight (3 x 8192 x 10) as two tiles of 12288 would.  The last pass stages k32 and k16 side by
-// side (16 KB more LDS): two workgroups.
+// records per thread: tiles of 8192, k32 and k16 staged side by side in LDS (48 KB), two workgroups per CU.
 constexpr int SEG48_ITEMS = 16;
 constexpr int SEG48_LAST_ITEMS = SEG48_ITEMS;
 
@@ -39,7 +36,7 @@ struct Seg48Args {
     const SegPlan* plan;
     int shift; u32 mask;                 // digit of the array this pass ranks by (ON16: k16, else k32)
     int next_shift; u32 next_mask;       // < 0: last pass
-    int next_on_other;                   // the next pass's digit lives in the OTHER array (pass 1 -> 2: counted when that array is stored)
+    int next_on16;                       // the next pass's digit lives in k16 (else k32)
     const u32* digit_base; u32* next_hist; u64* status; u32* ticket; u32 epoch; DeviceStatus* dstat;
     int begin_bit; u32 incl_mask;
 };
@@ -101,18 +98,17 @@ __device__ __forceinline__ void seg48_tile(const Seg48Args& a, const u32 flat, c
     }
     __syncthreads();
 
-    // 4. ranked array -> LDS at the tile-local sorted position (LAST: the other key array beside it)
+    // 4. both key arrays -> LDS at the tile-local sorted position, side by side (one staging round for the 6 key bytes:
+    //    with the other array as a third round of its own -- load, stage, barrier, store -- the passes ran at 3.8 TB/s, the last
+    //    pass, which always staged both, at 5.3)
     u32 pos[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
+        const u32 p = woff + j * WAVE;
         pos[j] = wh[rd[j] >> 16] + (rd[j] & 0xFFFFu);
-        if (FULL || (woff + j * WAVE) < tile_n) s_keys[pos[j]] = key[j];
-    }
-    if (LAST) {
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const u32 p = woff + j * WAVE;
-            if (FULL || p < tile_n) s_ext[pos[j]] = k16in[p];
+        if (FULL || p < tile_n) {
+            if (ON16) { s_ext[pos[j]] = (u16)key[j]; s_keys[pos[j]] = k32in[p]; }
+            else { s_keys[pos[j]] = key[j]; s_ext[pos[j]] = k16in[p]; }
         }
     }
     __syncthreads();
@@ -134,47 +130,22 @@ __device__ __forceinline__ void seg48_tile(const Seg48Args& a, const u32 flat, c
 
     // 6. coalesced stores per digit run
     u32 gidx[ITEMS];
-    const bool hist_here = has_next && !a.next_on_other;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
         const u32 p = k * BLOCK + tid;
         if (FULL || p < tile_n) {
-            const u32 kk = s_keys[p];
-            gidx[k] = s_gdelta[(kk >> a.shift) & a.mask] + p;
+            const u32 k32 = s_keys[p], k16 = s_ext[p];
+            gidx[k] = s_gdelta[((ON16 ? k16 : k32) >> a.shift) & a.mask] + p;
             if (LAST) {
-                a.keys_out64[gidx[k]] = ((u64)bucket << 56) | ((u64)kk << (a.begin_bit + 16)) | ((u64)s_ext[p] << a.begin_bit);
+                a.keys_out64[gidx[k]] = ((u64)bucket << 56) | ((u64)k32 << (a.begin_bit + 16)) | ((u64)k16 << a.begin_bit);
             } else {
-                if (ON16) a.k16_out[gidx[k]] = (u16)kk; else a.k32_out[gidx[k]] = kk;
-                if (hist_here) atomicAdd(&s_whist[(kk >> a.next_shift) & a.next_mask], 1u);
+                a.k32_out[gidx[k]] = k32;
+                a.k16_out[gidx[k]] = (u16)k16;
+                atomicAdd(&s_whist[((a.next_on16 ? k16 : k32) >> a.next_shift) & a.next_mask], 1u);
             }
         }
     }
-    __syncthreads();   // every read of s_keys is done
-    // 7. the other key array: loaded now, through the same LDS buffer, stored at the same places
-    if (!LAST) {
-        u32 oth[ITEMS];
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const u32 p = woff + j * WAVE;
-            if (ON16) oth[j] = (FULL || p < tile_n) ? k32in[p] : 0u;
-            else oth[j] = (FULL || p < tile_n) ? (u32)k16in[p] : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j)
-            if (FULL || (woff + j * WAVE) < tile_n) s_keys[pos[j]] = oth[j];
-        __syncthreads();
-        const bool hist_other = has_next && a.next_on_other;
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {
-            const u32 p = k * BLOCK + tid;
-            if (FULL || p < tile_n) {
-                const u32 v = s_keys[p];
-                if (ON16) a.k32_out[gidx[k]] = v; else a.k16_out[gidx[k]] = (u16)v;
-                if (hist_other) atomicAdd(&s_whist[(v >> a.next_shift) & a.next_mask], 1u);
-            }
-        }
-    }
-    sync_lds();   // LDS atomics above; every read of s_keys is done
+    sync_lds();   // LDS atomics above; every read of s_keys / s_ext is done
     if (has_next) {
         for (int i = tid; i < RADIX; i += BLOCK) {
             const u32 v = s_whist[i];
@@ -209,11 +180,11 @@ __device__ __forceinline__ void seg48_tile(const Seg48Args& a, const u32 flat, c
 }
 
 template <int BLOCK, int ITEMS, bool ON16, bool LAST>
-__global__ __launch_bounds__(BLOCK, LAST ? 4 : 6) void seg48_onesweep_kernel(Seg48Args a) {
+__global__ __launch_bounds__(BLOCK, 4) void seg48_onesweep_kernel(Seg48Args a) {
     constexpr int WAVES = BLOCK / WAVE;
     constexpr u32 TILE = BLOCK * ITEMS;
     __shared__ __attribute__((aligned(16))) u32 s_keys[TILE];   // reused for the other key array and the values
-    __shared__ u16 s_ext[LAST ? TILE : 2];
+    __shared__ u16 s_ext[TILE];
     __shared__ u32 s_whist[WAVES * RADIX];
     __shared__ u32 s_gdelta[RADIX];
     __shared__ u32 s_wsum[RADIX / WAVE];
@@ -326,7 +297,7 @@ inline int radix_sort_narrow48(RadixWorkspace& ws, NarrowWorkspace& nw, hipStrea
         a.shift = shift_of(p); a.mask = (1u << bits_of(p)) - 1u;
         a.next_shift = last ? -1 : shift_of(p + 1);
         a.next_mask = last ? 0u : ((1u << bits_of(p + 1)) - 1u);
-        a.next_on_other = (p == 1) ? 1 : 0;
+        a.next_on16 = (p + 1 < 2) ? 1 : 0;
         a.digit_base = nw.base;
         a.next_hist = last ? nullptr : nw.hist + (size_t)(p + 1) * RADIX * RADIX;
         a.status = ws.status; a.ticket = nw.tickets + p * NCHUNK; a.epoch = ws.epoch; a.dstat = ws.dstat;
