@@ -165,6 +165,27 @@ int sa_hip_index_replica_buffers(sa_hip_index* idx, sa_hip_replica_buffers* out)
 int sa_hip_index_replica_reserve(sa_hip_index* idx, const sa_hip_replica_layout* layout, sa_hip_replica_buffers* out);
 int sa_hip_index_replica_commit(sa_hip_index* idx);
 
+/* Multi-GPU lifecycle without PyTorch (the reference has no distributed code): one process
+ * per GPU, RCCL over xGMI, loaded at run time (no link-time dependency; a process that already holds a librccl.so --
+ * PyTorch ships one -- gets that copy).  Rank 0 calls sa_hip_comm_unique_id and ships the 128 bytes to the other ranks
+ * by whatever it has (MPI, a file, a socket: RCCL's own bootstrap contract); every rank then calls sa_hip_comm_create.
+ *   sa_hip_comm_replicate_index  root: a built index; other ranks: an empty handle of sufficient capacity, searchable
+ *                                afterwards -- one broadcast per buffer (text, SA, key array, directory) straight into
+ *                                reserved buffers, nothing rebuilt (sa_hip_index_replica_*); *bytes_out = bytes moved
+ *   sa_hip_comm_allgather_ranges every rank's pairs_per_rank (first, last) pairs -> recv_dev[nranks][pairs_per_rank], on the
+ *                                index's own stream (ordered after the search that produced them; asynchronous until
+ *                                sa_hip_index_sync)
+ * torch.distributed drives the same replica entry points in suffixarray_amd/distributed.py. */
+#define SA_HIP_COMM_ID_BYTES 128
+typedef struct sa_hip_comm sa_hip_comm;
+int sa_hip_comm_unique_id(void* id128);
+int sa_hip_comm_create(sa_hip_comm** out, const void* id128, int nranks, int rank, int device);
+void sa_hip_comm_destroy(sa_hip_comm* comm);
+int sa_hip_comm_rank(const sa_hip_comm* comm);
+int sa_hip_comm_size(const sa_hip_comm* comm);
+int sa_hip_comm_replicate_index(sa_hip_comm* comm, sa_hip_index* idx, int root, uint64_t* bytes_out);
+int sa_hip_comm_allgather_ranges(sa_hip_comm* comm, sa_hip_index* idx, const void* send_dev, uint64_t pairs_per_rank, void* recv_dev);
+
 uint64_t sa_hip_index_n(const sa_hip_index* idx);
 uint32_t sa_hip_index_max_suffix_length(const sa_hip_index* idx);
 /* Device pointers owned by the index: text (n bytes + zero padding) and SA (uint32[n]). */

@@ -31,6 +31,8 @@ EXPORTS = [
     "sa_hip_csv_index_column_index", "sa_hip_csv_index_column_name", "sa_hip_csv_index_row_tables",
     "sa_hip_get_substring_positions_file", "sa_hip_get_matching_records_file", "sa_hip_get_matching_records", "sa_hip_free_records",
     "sa_hip_init_suffix_array_byte_idxs", "sa_hip_free_suffix_array",
+    "sa_hip_comm_unique_id", "sa_hip_comm_create", "sa_hip_comm_destroy", "sa_hip_comm_rank", "sa_hip_comm_size",
+    "sa_hip_comm_replicate_index", "sa_hip_comm_allgather_ranges",
     "sa_hip_index_replica_layout", "sa_hip_index_replica_buffers", "sa_hip_index_replica_reserve", "sa_hip_index_replica_commit",
     "sa_hip_index_query_stats", "sa_hip_csv_extract_column", "sa_hip_csv_free", "sa_hip_synth_csv", "sa_hip_sort_pairs", "sa_hip_synth_uniform27", "sa_hip_last_error", "sa_hip_version",
 ]
@@ -150,6 +152,20 @@ def lib():
     L.sa_hip_index_load.argtypes = [vp, vp, vp, u64, u32]
     L.sa_hip_index_load_device.restype = C.c_int
     L.sa_hip_index_load_device.argtypes = [vp, vp, vp, u64, u32]
+    L.sa_hip_comm_unique_id.restype = C.c_int
+    L.sa_hip_comm_unique_id.argtypes = [vp]
+    L.sa_hip_comm_create.restype = C.c_int
+    L.sa_hip_comm_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int]
+    L.sa_hip_comm_destroy.restype = None
+    L.sa_hip_comm_destroy.argtypes = [vp]
+    L.sa_hip_comm_rank.restype = C.c_int
+    L.sa_hip_comm_rank.argtypes = [vp]
+    L.sa_hip_comm_size.restype = C.c_int
+    L.sa_hip_comm_size.argtypes = [vp]
+    L.sa_hip_comm_replicate_index.restype = C.c_int
+    L.sa_hip_comm_replicate_index.argtypes = [vp, vp, C.c_int, C.POINTER(u64)]
+    L.sa_hip_comm_allgather_ranges.restype = C.c_int
+    L.sa_hip_comm_allgather_ranges.argtypes = [vp, vp, vp, u64, vp]
     L.sa_hip_index_replica_layout.restype = C.c_int
     L.sa_hip_index_replica_layout.argtypes = [vp, C.POINTER(ReplicaLayout)]
     L.sa_hip_index_replica_buffers.restype = C.c_int
@@ -479,6 +495,48 @@ class DeviceIndex:
     def query_batch_device_fixed(self, patterns_dev_ptr, pattern_len, q, out_dev_ptr):
         """q patterns of pattern_len bytes each, packed back to back in device memory (no offsets array)."""
         check(self._lib.sa_hip_query_batch_device_fixed(self._h, patterns_dev_ptr, pattern_len, q, out_dev_ptr))
+
+
+class Comm:
+    """sa_hip_comm: RCCL communicator of the C ABI (one process per GPU; no torch involved)."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib().sa_hip_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, unique_id: bytes, nranks, rank, device=0):
+        self._lib = lib()
+        self._h = C.c_void_p()
+        check(self._lib.sa_hip_comm_create(C.byref(self._h), unique_id, nranks, rank, device))
+
+    @property
+    def rank(self):
+        return self._lib.sa_hip_comm_rank(self._h)
+
+    @property
+    def size(self):
+        return self._lib.sa_hip_comm_size(self._h)
+
+    def replicate_index(self, idx, root=0):
+        n = C.c_uint64(0)
+        check(self._lib.sa_hip_comm_replicate_index(self._h, idx._h, root, C.byref(n)))
+        return int(n.value)
+
+    def allgather_ranges(self, idx, send_dev_ptr, pairs_per_rank, recv_dev_ptr):
+        check(self._lib.sa_hip_comm_allgather_ranges(self._h, idx._h, send_dev_ptr, pairs_per_rank, recv_dev_ptr))
+
+    def close(self):
+        if self._h:
+            self._lib.sa_hip_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 # -- libsais- / engine-compatible one-shot wrappers ----------------------------------------------

@@ -994,7 +994,7 @@ struct Builder {
     CodeMap qmap;
     int q_b = 0, q_k0 = 0, q_dbits = 0;
     bool dir_ready = false;   // the directory in qdir belongs to qkeys
-    bool sector_search = true;    // SA_HIP_SECTOR_SEARCH: interpolated sector scan inside a directory bucket (sa_query.hpp)
+    int sector_search = 1;        // SA_HIP_SECTOR_SEARCH: interpolated scan inside a directory bucket (sa_query.hpp): 1 = 64-byte windows, 2 = 32-byte windows, 0 = binary search
 
     // Characters in the initial key.  Enough that, for an i.i.d. text with this byte
     // distribution, about 2 % of the suffixes still share their key (collision probability
@@ -1058,7 +1058,7 @@ struct Builder {
         if (const char* e = diag_env("SA_HIP_LOCAL_ROUNDS")) local_rounds = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_GROUP_FINISH")) group_finish = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_PILOT")) use_pilot = atoi(e) != 0;
-        if (const char* e = diag_env("SA_HIP_SECTOR_SEARCH")) sector_search = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_SECTOR_SEARCH")) sector_search = atoi(e);
         if (const char* e = diag_env("SA_HIP_FIN_COUNT_MAX")) fin_count_max = (u32)atoi(e);
         if (const char* e = diag_env("SA_HIP_BIG_ROUND_CHARS")) big_round_chars = atoi(e);
         if (const char* e = diag_env("SA_HIP_FIN_RADIX_CHARS")) fin_radix_chars = atoi(e);

@@ -15,6 +15,7 @@
 #include "host_io.hpp"
 #include "rows_device.hpp"
 #include "host_index.hpp"
+#include "comm_rccl.hpp"
 #include <memory>
 #include <chrono>
 
@@ -48,6 +49,13 @@ struct sa_hip_index {
     std::unique_ptr<HostIndex> host;   // set: the opt-in no-GPU path of config 1 (host_index.hpp); nothing below touches HIP then
     bool receiving = false;        // sa_hip_index_replica_reserve .. _commit: the buffers are being filled by the caller
     sa_hip_replica_layout pending{};
+};
+
+// multi-GPU lifecycle (comm_rccl.hpp): one communicator per process / GPU
+struct sa_hip_comm {
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0, device = 0;
+    hipStream_t stream = nullptr;   // replication runs here; the range gather runs on the searching index's stream
 };
 
 // CSV-mode index (SuffixArrayIndex of the reference, engine.h:163-172): the device index over one column + the row
@@ -99,7 +107,7 @@ int launch_query(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q
     a.keys = idx->b.qkeys;
     a.keys32 = idx->b.qkeys32;
     a.lo_shift = idx->b.q_lo_shift;
-    a.sector_search = idx->b.sector_search ? 1 : 0;
+    a.sector_search = idx->b.sector_search;
     a.dir = idx->b.qdir.as<u32>();
     a.b = idx->b.q_b; a.k0 = idx->b.q_k0; a.dbits = idx->b.q_dbits;
     SA_HIP_CHECK(hipEventRecord(ev[0], idx->stream));
@@ -439,6 +447,98 @@ int sa_hip_index_replica_commit(sa_hip_index* idx) {
     b.qkeys32 = l.key_bytes == 4 ? b.keys0.as<u32>() : nullptr;
     b.dir_ready = l.key_bytes != 0;
     idx->has_index = true;
+    return 0;
+}
+
+// ---- multi-GPU lifecycle without PyTorch -----------------------------------------------------
+
+int sa_hip_comm_unique_id(void* id128) {
+    if (!id128) return fail(SA_HIP_EINVAL, "sa_hip_comm_unique_id: NULL argument");
+    RcclApi& r = rccl_api();
+    if (!r.ok) return fail(SA_HIP_EHIP, "sa_hip_comm: librccl.so could not be loaded");
+    static_assert(sizeof(ncclUniqueId) == SA_HIP_COMM_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    SA_RCCL_CHECK(r.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return 0;
+}
+
+int sa_hip_comm_create(sa_hip_comm** out, const void* id128, int nranks, int rank, int device) {
+    if (!out || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(SA_HIP_EINVAL, "sa_hip_comm_create: invalid arguments");
+    *out = nullptr;
+    RcclApi& r = rccl_api();
+    if (!r.ok) return fail(SA_HIP_EHIP, "sa_hip_comm: librccl.so could not be loaded");
+    int rc = set_device(device);
+    if (rc) return rc;
+    sa_hip_comm* c = new (std::nothrow) sa_hip_comm();
+    if (!c) return fail(SA_HIP_ENOMEM, "sa_hip_comm_create: host allocation");
+    c->nranks = nranks; c->rank = rank; c->device = device;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclResult_t nr = r.CommInitRank(&c->comm, nranks, id, rank);
+    if (nr != ncclSuccess) { delete c; return fail(SA_HIP_EHIP, "ncclCommInitRank", r.GetErrorString(nr)); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { (void)r.CommDestroy(c->comm); delete c; return fail(SA_HIP_EHIP, "hipStreamCreate"); }
+    *out = c;
+    return 0;
+}
+
+void sa_hip_comm_destroy(sa_hip_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->comm) (void)rccl_api().CommDestroy(c->comm);
+    delete c;
+}
+
+int sa_hip_comm_rank(const sa_hip_comm* c) { return c ? c->rank : -1; }
+int sa_hip_comm_size(const sa_hip_comm* c) { return c ? c->nranks : 0; }
+
+int sa_hip_comm_replicate_index(sa_hip_comm* c, sa_hip_index* idx, int root, uint64_t* bytes_out) {
+    if (!c || !idx || root < 0 || root >= c->nranks) return fail(SA_HIP_EINVAL, "sa_hip_comm_replicate_index: invalid arguments");
+    if (idx->host) return fail(SA_HIP_EHIP, "sa_hip_comm_replicate_index: the host path (no HIP device) has no device buffers");
+    RcclApi& r = rccl_api();
+    int rc = set_device(c->device);
+    if (rc) return rc;
+    // the layout first (a small struct through a device bounce buffer), then the four buffers where they lie
+    sa_hip_replica_layout lay;
+    memset(&lay, 0, sizeof lay);
+    if (c->rank == root && (rc = sa_hip_index_replica_layout(idx, &lay))) return rc;
+    void* bounce = nullptr;
+    SA_HIP_CHECK(hipMalloc(&bounce, sizeof lay));
+    auto body = [&]() -> int {
+        SA_HIP_CHECK(hipMemcpyAsync(bounce, &lay, sizeof lay, hipMemcpyHostToDevice, c->stream));
+        SA_RCCL_CHECK(r.Broadcast(bounce, bounce, sizeof lay, ncclUint8, root, c->comm, c->stream));
+        SA_HIP_CHECK(hipMemcpyAsync(&lay, bounce, sizeof lay, hipMemcpyDeviceToHost, c->stream));
+        SA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        sa_hip_replica_buffers b;
+        int rc2 = (c->rank == root) ? sa_hip_index_replica_buffers(idx, &b) : sa_hip_index_replica_reserve(idx, &lay, &b);
+        if (rc2) return rc2;
+        void* ptr[4] = {b.text, b.sa, b.keys, b.dir};
+        const u64 len[4] = {b.text_bytes, b.sa_bytes, b.keys_bytes, b.dir_bytes};
+        u64 total = 0;
+        for (int i = 0; i < 4; ++i) {
+            if (!len[i]) continue;
+            SA_RCCL_CHECK(r.Broadcast(ptr[i], ptr[i], (size_t)len[i], ncclUint8, root, c->comm, c->stream));
+            total += len[i];
+        }
+        SA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (bytes_out) *bytes_out = total;
+        return (c->rank == root) ? 0 : sa_hip_index_replica_commit(idx);
+    };
+    rc = body();
+    (void)hipFree(bounce);
+    return rc;
+}
+
+int sa_hip_comm_allgather_ranges(sa_hip_comm* c, sa_hip_index* idx, const void* send_dev, uint64_t pairs_per_rank, void* recv_dev) {
+    if (!c || !idx || ((!send_dev || !recv_dev) && pairs_per_rank)) return fail(SA_HIP_EINVAL, "sa_hip_comm_allgather_ranges: NULL argument");
+    if (idx->host) return fail(SA_HIP_EHIP, "sa_hip_comm_allgather_ranges: the host path (no HIP device) has no device buffers");
+    if (pairs_per_rank == 0) return 0;
+    int rc = set_device(c->device);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(idx->mu);
+    // on the index's own stream: ordered after the search that produced send_dev, no host synchronisation in between
+    SA_RCCL_CHECK(rccl_api().AllGather(send_dev, recv_dev, (size_t)pairs_per_rank * sizeof(sa_hip_pair_u32), ncclUint8, c->comm, idx->stream));
     return 0;
 }
 

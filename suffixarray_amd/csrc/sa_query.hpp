@@ -95,7 +95,7 @@ struct QueryArgs {
     int b, k0, dbits;
     const u32* keys32;      // NARROW: K[j] = (top digit of j's directory bucket << 56) | (keys32[j] << lo_shift)
     int lo_shift;
-    int sector_search;      // 1: interpolated sector scan inside the directory bucket (below); 0: plain binary search
+    int sector_search;      // 1: interpolated sector scan inside the directory bucket (below), 64-byte windows; 2: 32-byte windows; 0: plain binary search
 };
 
 // The batch is bound by the NUMBER of 64-byte sectors it requests, not by bytes or by the dependent-load chain
@@ -106,27 +106,31 @@ struct QueryArgs {
 // the first one brings in); sorted keys tell at once whether the bound lies inside, to the left or to the right.
 // Returns the first slot in [l, h) whose key is >= t (h if none).  win / wbase: the keys of the sector the answer was
 // found in and the slot of win[0] (for the upper bound, which usually lies in the same sector).
-template <typename KT>
+// WBYTES: 64 (a whole sector) or 32 (half of one).  Round 3 (tools/gatherbench sweep, profiles/r03_gather_sweep.log): random
+// reads from a footprint beyond the Infinity Cache are served at ~1.65 TB/s in 32-BYTE granules whatever the request size
+// (4-byte reads 51 G/s, 64-byte reads 26 G/s, 128-byte reads 13 G/s) -- a 64-byte window costs two granules, a 32-byte
+// window one, and the interpolated estimate is usually within the 8 (u32) keys around it.
+template <typename KT, int WBYTES>
 struct SectorWindow {
-    static constexpr int W = 64 / (int)sizeof(KT);
+    static constexpr int W = WBYTES / (int)sizeof(KT);
     KT k[W];
     u64 base;    // slot of k[0] (a multiple of W)
 };
-template <typename KT>
-__device__ __forceinline__ void load_sector(const KT* __restrict__ K, u64 base, SectorWindow<KT>& w) {
+template <typename KT, int WBYTES>
+__device__ __forceinline__ void load_sector(const KT* __restrict__ K, u64 base, SectorWindow<KT, WBYTES>& w) {
     w.base = base;
     const uint4* p = reinterpret_cast<const uint4*>(K + base);   // K is 256-byte aligned and padded to whole sectors
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < WBYTES / 16; ++i) {
         const uint4 v = p[i];
         if (sizeof(KT) == 4) { w.k[4 * i] = (KT)v.x; w.k[4 * i + 1] = (KT)v.y; w.k[4 * i + 2] = (KT)v.z; w.k[4 * i + 3] = (KT)v.w; }
         else { w.k[2 * i] = (KT)(((u64)v.y << 32) | v.x); w.k[2 * i + 1] = (KT)(((u64)v.w << 32) | v.z); }
     }
 }
 // first slot in [l, h) with key >= t (STRICT: > t), starting at the sector of `est`; l < h
-template <bool STRICT, typename KT>
-__device__ __forceinline__ u64 sector_bound(const KT* __restrict__ K, u64 l, u64 h, KT t, u64 est, SectorWindow<KT>& w, bool have_window) {
-    constexpr int W = SectorWindow<KT>::W;
+template <bool STRICT, typename KT, int WBYTES>
+__device__ __forceinline__ u64 sector_bound(const KT* __restrict__ K, u64 l, u64 h, KT t, u64 est, SectorWindow<KT, WBYTES>& w, bool have_window) {
+    constexpr int W = SectorWindow<KT, WBYTES>::W;
     u64 lo = l, hi = h;   // the bound lies in [lo, hi]
     u64 base = est & ~(u64)(W - 1);
     for (int step = 0; step < 3 && lo < hi; ++step) {
@@ -226,9 +230,15 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
                         est = l + (((frac >> down) * (h - l)) >> (sb - down));
                         if (est >= h) est = h - 1;
                     }
-                    SectorWindow<KT> w;
-                    lo = sector_bound<false>(K, l, h, t_lo, est, w, false);
-                    hi = (lo < h) ? sector_bound<true>(K, lo, h, t_hi2, lo, w, true) : lo;
+                    if (a.sector_search == 2) {   // (uniform) 32-byte windows
+                        SectorWindow<KT, 32> w;
+                        lo = sector_bound<false>(K, l, h, t_lo, est, w, false);
+                        hi = (lo < h) ? sector_bound<true>(K, lo, h, t_hi2, lo, w, true) : lo;
+                    } else {
+                        SectorWindow<KT, 64> w;
+                        lo = sector_bound<false>(K, l, h, t_lo, est, w, false);
+                        hi = (lo < h) ? sector_bound<true>(K, lo, h, t_hi2, lo, w, true) : lo;
+                    }
                     searched = true;
                 }
                 // first slot with K >= key_lo

@@ -127,3 +127,31 @@ def test_replica_commit_refuses_what_would_send_the_search_out_of_bounds(gpu):
         with gpu.DeviceIndex(1000, 0) as small:
             with pytest.raises(gpu.SaHipError):
                 small.replica_reserve(lay)                                         # beyond the handle's capacity
+
+
+def test_comm_c_abi_world_size_1(gpu, oracle):
+    """sa_hip_comm_*: RCCL through the C ABI, no torch.distributed -- unique id, communicator, index replication entry point
+    (at world size 1 the root's part of it) and the gather of the range pairs on the index's own stream, ordered after the
+    search without a host synchronisation in between."""
+    import torch
+    text = synth.d1_uniform27(4_400_000)
+    q, m = 50_000, 12
+    fb, fo = synth.query_batch(text, q, m, seed=3)
+    dev = torch.device("cuda", 0)
+    with gpu.Comm(gpu.Comm.unique_id(), 1, 0, 0) as comm, gpu.DeviceIndex(text.size, 0) as idx:
+        assert comm.rank == 0 and comm.size == 1
+        idx.build(text)
+        moved = comm.replicate_index(idx, root=0)
+        assert moved >= 9 * text.size
+        pat = torch.from_numpy(np.concatenate([fb, np.zeros(64, np.uint8)])).to(dev)
+        out = torch.full((2 * q,), -1, dtype=torch.int32, device=dev)
+        rec = torch.full((2 * q,), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        idx.query_batch_device_fixed(pat.data_ptr(), m, q, out.data_ptr())
+        comm.allgather_ranges(idx, out.data_ptr(), q, rec.data_ptr())     # no sync in between: same stream
+        idx.sync()
+        got = rec.cpu().numpy().view(np.uint32).reshape(q, 2)
+        exp = oracle.query_batch(text, idx.sa_u32(), 0xFFFFFFFF, (fb, fo))
+        assert np.array_equal(got[:, 0], exp["first"]) and np.array_equal(got[:, 1], exp["second"])
+        with pytest.raises(gpu.SaHipError):
+            comm.replicate_index(idx, root=3)
