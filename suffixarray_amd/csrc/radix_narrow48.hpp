@@ -114,8 +114,10 @@ __device__ __forceinline__ void seg48_tile(const Seg48Args& a, const u32 flat, c
     __syncthreads();
 
     // 5. look-back inside the bucket; the other lanes clear the next-digit histogram (reuses s_whist)
+    // (the histogram is kept in WAVES lane-selected copies: on word / name text the digits above the one being sorted are
+    //  heavily skewed, and 64 lanes of a wave adding to ONE LDS word serialise)
     const bool has_next = !LAST;
-    if (has_next) for (int i = tid; i < RADIX; i += BLOCK) s_whist[i] = 0;
+    if (has_next) for (int i = tid; i < WAVES * RADIX; i += BLOCK) s_whist[i] = 0;
     if (tid < RADIX) {
         u32 prefix = 0;
         if (flat > first_flat) {
@@ -141,14 +143,16 @@ __device__ __forceinline__ void seg48_tile(const Seg48Args& a, const u32 flat, c
             } else {
                 a.k32_out[gidx[k]] = k32;
                 a.k16_out[gidx[k]] = (u16)k16;
-                atomicAdd(&s_whist[((a.next_on16 ? k16 : k32) >> a.next_shift) & a.next_mask], 1u);
+                atomicAdd(&s_whist[(u32)(lane & (WAVES - 1)) * RADIX + (((a.next_on16 ? k16 : k32) >> a.next_shift) & a.next_mask)], 1u);
             }
         }
     }
     sync_lds();   // LDS atomics above; every read of s_keys / s_ext is done
     if (has_next) {
         for (int i = tid; i < RADIX; i += BLOCK) {
-            const u32 v = s_whist[i];
+            u32 v = 0;
+#pragma unroll
+            for (int c = 0; c < WAVES; ++c) v += s_whist[c * RADIX + i];
             if (v) atomicAdd(&a.next_hist[bucket * RADIX + i], v);
         }
     }

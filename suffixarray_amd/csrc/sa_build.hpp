@@ -31,6 +31,7 @@
 #include "radix_narrow48.hpp"
 #include "round_sort.hpp"
 #include "group_finish.hpp"
+#include "period_finish.hpp"
 
 namespace sa {
 
@@ -965,6 +966,9 @@ struct Builder {
     bool fin_useful = true;           // per build: cleared when a run resolves less than a quarter of what it looked at
     bool use_pilot = true;            // SA_HIP_PILOT: 0 = initial key length from the byte distribution alone
     DevBuf fin_flag;                  // u8[M]: per list position, final / head marks of the finisher
+    bool period_finish = true;        // SA_HIP_PERIOD_FINISH: arithmetic groups inside one periodic run are ordered in one step (period_finish.hpp)
+    int per_skip = 0, per_fails = 0;  // per build: an attempt that orders less than an eighth of the active set is repeated only after 2, 4, 8 ... rounds
+    DevBuf per_gd, per_bad, per_table, per_dec, per_tf, per_carry;
     // the slot lists of the active set: the next compaction writes into lst_nxt.  With an int64 copy to keep up to date the
     // FIRST list (apos0) is left alone -- it names every slot that is written after the sort -- and later lists
     // ping-pong between apos1 and apos2.
@@ -1058,6 +1062,7 @@ struct Builder {
         if (const char* e = diag_env("SA_HIP_LOCAL_ROUNDS")) local_rounds = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_GROUP_FINISH")) group_finish = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_PILOT")) use_pilot = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_PERIOD_FINISH")) period_finish = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_SECTOR_SEARCH")) sector_search = atoi(e);
         if (const char* e = diag_env("SA_HIP_FIN_COUNT_MAX")) fin_count_max = (u32)atoi(e);
         if (const char* e = diag_env("SA_HIP_BIG_ROUND_CHARS")) big_round_chars = atoi(e);
@@ -1092,7 +1097,7 @@ struct Builder {
     void destroy() {
         DevBuf* all[] = {&text, &keys0, &keys1, &vals0, &vals1, &flags, &counts, &small, &isa, &apos0, &apos1, &apos2, &aidx,
                          &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir, &dbg, &done, &pilot,
-                         &gstart, &loc_tiles, &big_keys, &big_vals, &fin_flag};
+                         &gstart, &loc_tiles, &big_keys, &big_vals, &fin_flag, &per_gd, &per_bad, &per_table, &per_dec, &per_tf, &per_carry};
         for (DevBuf* b : all) b->release();
         radix.destroy();
         narrow.destroy();
@@ -1460,6 +1465,69 @@ struct Builder {
         return 0;
     }
 
+    // Long repeats (period_finish.hpp): tied groups whose members form an arithmetic progression inside one periodic run are
+    // ordered by one comparison.  In: the active list (lst_cur, aidx, gid) of M records in G groups.  Out: M, G, lists compacted.
+    int run_period_finisher(bool have_isa, u32& M, u32& G, u32* tot) {
+        int rc;
+        if ((rc = gstart.ensure(((size_t)G + 2) * 4))) return rc;
+        if ((rc = per_gd.ensure((size_t)G * 4 + 64))) return rc;
+        if ((rc = per_bad.ensure((size_t)G + 64))) return rc;
+        if ((rc = per_dec.ensure((size_t)G + 64))) return rc;
+        if ((rc = per_table.ensure((size_t)PER_TABLE * sizeof(uint2)))) return rc;
+        if ((rc = done.ensure((size_t)M + 64))) return rc;
+        const u32 ntiles = div_up(n, PER_TILE);
+        if ((rc = per_tf.ensure((size_t)ntiles * 4 + 64))) return rc;
+        if ((rc = per_carry.ensure((size_t)ntiles * 4 + 64))) return rc;
+        SA_HIP_CHECK(hipMemsetAsync(done.p, 0, (size_t)M, stream));
+        hipLaunchKernelGGL(group_starts_kernel, dim3(stream_grid(M, 1024)), dim3(256), 0, stream, gid.as<u32>(), M, G, gstart.as<u32>());
+        hipLaunchKernelGGL(per_init_kernel, dim3(stream_grid(G, 256)), dim3(256), 0, stream, aidx.as<u32>(), gstart.as<u32>(), G,
+                           per_gd.as<u32>(), per_bad.as<u8>());
+        hipLaunchKernelGGL(per_classify_kernel, dim3(stream_grid(M, 1024)), dim3(256), 0, stream, aidx.as<u32>(), gid.as<u32>(), gstart.as<u32>(), M,
+                           per_gd.as<u32>(), per_bad.as<u8>());
+        u32* best_dev = reinterpret_cast<u32*>(small.as<u8>() + 3720);
+        u64 covered = 0;
+        for (int iter = 0; iter < 4; ++iter) {
+            SA_HIP_CHECK(hipMemsetAsync(per_table.p, 0, (size_t)PER_TABLE * sizeof(uint2), stream));
+            hipLaunchKernelGGL(per_hist_kernel, dim3(stream_grid(G, 256)), dim3(256), 0, stream, gstart.as<u32>(), G, per_gd.as<u32>(),
+                               per_bad.as<u8>(), per_table.as<uint2>());
+            hipLaunchKernelGGL(per_pick_kernel, dim3(1), dim3(1024), 0, stream, per_table.as<uint2>(), best_dev);
+            u32 best[2] = {0, 0};
+            SA_HIP_CHECK(hipMemcpyAsync(best, best_dev, 8, hipMemcpyDeviceToHost, stream));
+            SA_HIP_CHECK(hipStreamSynchronize(stream));
+            if (debug_rounds) fprintf(stderr, "[sa_hip] period finisher M=%u G=%u: difference %u covers %u records\n", M, G, best[0], best[1]);
+            if (best[0] == 0 || (u64)best[1] * 8 < M) break;   // nothing periodic enough (left)
+            covered += best[1];
+            const u64 d = best[0];
+            hipLaunchKernelGGL(per_tile_first_kernel, dim3(ntiles), dim3(256), 0, stream, text.as<u8>(), n, d, per_tf.as<u32>());
+            hipLaunchKernelGGL(per_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, per_tf.as<u32>(), ntiles, per_carry.as<u32>());
+            PerArgs a;
+            a.text = text.as<u8>(); a.n = n; a.d = d;
+            a.aidx = aidx.as<u32>(); a.apos = lst_cur; a.gid = gid.as<u32>(); a.gstart = gstart.as<u32>(); a.gd = per_gd.as<u32>();
+            a.bad = per_bad.as<u8>(); a.G = G; a.M = M; a.tile_first = per_tf.as<u32>(); a.carry = per_carry.as<u32>(); a.dec = per_dec.as<u8>();
+            a.sa = sa; a.gflags = flags.as<u8>(); a.done = done.as<u8>(); a.isa = have_isa ? isa.as<u32>() : nullptr;
+            hipLaunchKernelGGL(per_decide_kernel, dim3(stream_grid((u64)G * 64, 256)), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(per_apply_kernel, dim3(stream_grid(M, 1024)), dim3(256), 0, stream, a);
+        }
+        if ((u64)covered * 8 < M) { per_skip = 2 << per_fails++; return 0; }   // nothing was attempted: the lists are untouched
+        const u32 tiles = div_up(M, BLD_TILE);
+        hipLaunchKernelGGL(tiny_flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, gid.as<u32>(), done.as<u8>(), M, lf.as<u8>(),
+                           counts.as<uint2>());
+        if ((rc = scan_counts(tiles, tot))) return rc;
+        stats.period_resolved += (u64)M - tot[0];
+        if (debug_rounds) fprintf(stderr, "[sa_hip] period finisher: resolved %u of %u -> M'=%u G'=%u\n", M - tot[0], M, tot[0], tot[1]);
+        if ((u64)(M - tot[0]) * 8 < M) per_skip = 2 << per_fails++;   // (chains cut by the end of a run split up in later rounds)
+        if (tot[0] < M) {
+            if (tot[0]) {
+                SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
+                launch_compact(lf.as<u8>(), M, tot[0], lst_cur, ridx0.as<u32>(), lst_nxt, aidx.as<u32>(), gid.as<u32>());
+                swap_lists();
+            }
+            M = tot[0];
+            G = tot[1];
+        }
+        return 0;
+    }
+
     // The device build.  Text already resident in text.p[0..n_).
     // sa64_out (may be null): the suffix array also in libsais64 layout, int64[n] in a device buffer of the caller.
     // On the narrow-record plan the sort's last pass writes it next to the u32 array and the slots refined afterwards
@@ -1469,6 +1537,7 @@ struct Builder {
         memset(&stats, 0, sizeof stats);
         local_records = big_records = 0;
         fin_useful = true;
+        per_skip = per_fails = 0;
         radix.reset_stats();
         max_suffix_length = L;
         stats.n = n_;
@@ -1628,6 +1697,15 @@ struct Builder {
                 if ((rc = run_group_finisher(map, b, L, h, M, G, tot))) return rc;
                 if (!M) break;
                 finisher_ran = fin_useful;
+            }
+            // long repeats -- the finisher gave up, doubling is under way, or the groups are far larger than a tile: groups that
+            // are arithmetic progressions inside one periodic run are ordered in one step (full suffix arrays only)
+            if (period_finish && L == 0 && M >= 64 && per_fails < 8 && (!fin_useful || have_isa || (u64)M > (u64)G * (FIN_CAP / 2))) {
+                if (per_skip > 0) --per_skip;
+                else {
+                    if ((rc = run_period_finisher(have_isa, M, G, tot))) return rc;
+                    if (!M) break;
+                }
             }
             const int gb = bits_for(G);
             // Chunk rounds read the next characters from the text; doubling rounds need the inverse suffix array

@@ -90,8 +90,10 @@ def test_truncated_mode_bit_exact_vs_oracle(gpu, oracle):
     check_truncated_order(t, sa, 32)
 
 
-def test_doubling_path_is_exercised(gpu, oracle):
-    """Long repeats must go through chunk rounds AND doubling rounds."""
+def test_doubling_path_is_exercised(gpu, oracle, monkeypatch):
+    """Long repeats must go through chunk rounds AND doubling rounds (with the periodic-run shortcut switched off: it would
+    order these groups in one step, test_period_finisher_matches_doubling_rounds)."""
+    monkeypatch.setenv("SA_HIP_PERIOD_FINISH", "0")
     t = cases.small_texts()["repeat_block"]
     with gpu.DeviceIndex(t.size, 0) as idx:
         idx.build(t)
@@ -201,6 +203,56 @@ def test_narrow48_record_sort_matches_wide_sort(gpu, oracle, monkeypatch):
     monkeypatch.delenv("SA_HIP_NARROW48", raising=False)
 
 
+def test_period_finisher_matches_doubling_rounds(gpu, oracle, monkeypatch):
+    """Long repeats (period_finish.hpp): tied groups whose members form an arithmetic progression inside one periodic run are
+    ordered by ONE comparison instead of ~log2(n) doubling rounds over everything.  Same suffix array as with the shortcut
+    switched off (SA_HIP_PERIOD_FINISH=0), verified on the device, equal to the oracle's: all-'a', periods 2 / 3 / 7, a random
+    block repeated (two alphabets), a Fibonacci string (several differences), a block repeat with one mutated character
+    (chains cut by the end of a run: left to the rounds), two periodic regions with different periods, a word text with a
+    60 000-character run, near-random text (nothing to do), and the int64 copy of a fused 64-bit build on top of it."""
+    import torch
+    from suffixarray_amd import synth
+    rng = np.random.default_rng(21)
+    blk26 = np.tile(rng.integers(97, 123, 300_000, dtype=np.uint8), 16)
+    blk4 = np.tile(rng.integers(97, 101, 70_000, dtype=np.uint8), 40)
+    mut = blk26.copy()
+    mut[2_345_678] = ord("!")
+    two = np.concatenate([synth.periodic(1_500_000, 2), np.frombuffer(b"zq", np.uint8), synth.periodic(1_600_000, 7), synth.all_same(900_000, 99)])
+    run = synth.d2_words(5_000_000).copy()
+    run[2_000_000:2_060_000] = ord("q")
+    runs = [("all_a", synth.all_same(3_000_000), True), ("p2", synth.periodic(2_000_000, 2), True), ("p3", synth.periodic(2_000_001, 3), True),
+            ("p7", synth.periodic(1_000_003, 7), True), ("blk26", blk26, True), ("blk4", blk4, True), ("fib", synth.fibonacci(2_178_309), True),
+            ("mut", mut, None), ("two", two, True), ("run", run, True), ("small_blk", cases.small_texts()["repeat_block"], True),
+            ("all_a_70000", cases.small_texts()["all_a_70000"], True), ("d1", synth.d1_uniform27(4_400_000), False)]
+    for name, t, expect in runs:
+        got, stats = {}, {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SA_HIP_PERIOD_FINISH", mode)
+            with gpu.DeviceIndex(t.size, 0) as idx:
+                idx.build(t)
+                stats[mode] = idx.build_stats()
+                assert idx.verify() == 0, (name, mode, stats[mode])
+                got[mode] = idx.sa_u32().copy()
+                if mode == "1" and name in ("blk26", "run", "fib"):
+                    out = torch.full((t.size,), -7, dtype=torch.int64, device="cuda:0")
+                    torch.cuda.synchronize()
+                    idx.build_device64(idx.text_dev, t.size, out.data_ptr(), 0)
+                    idx.sync()
+                    assert np.array_equal(out.cpu().numpy(), got[mode].astype(np.int64)), name
+        assert np.array_equal(got["1"], got["0"]), (name, stats)
+        assert (expect is None or (stats["1"]["period_resolved"] > 0) == expect) and stats["0"]["period_resolved"] == 0, (name, stats["1"])
+        if t.size <= 5_000_000:
+            assert np.array_equal(got["1"], oracle.sais(t).astype(np.uint32)), name
+        if name in ("all_a", "blk26", "blk4", "p2"):
+            assert stats["1"]["rounds"] + 4 < stats["0"]["rounds"], (name, stats["1"]["rounds"], stats["0"]["rounds"])
+    # truncated builds never take the shortcut
+    monkeypatch.setenv("SA_HIP_PERIOD_FINISH", "1")
+    with gpu.DeviceIndex(blk4.size, 0) as idx:
+        idx.build(blk4, 40)
+        assert idx.build_stats()["period_resolved"] == 0 and idx.verify() == 0
+        assert np.array_equal(idx.sa_u32(), oracle.truncated_sa(blk4, 40))
+
+
 def test_rounds_sorted_in_lds_match_global_sort(gpu, oracle, monkeypatch):
     """Refinement rounds are sorted group-wise in LDS (round_sort.hpp: tiles of whole groups, 12-bit local group ids,
     packed and unpacked record form, groups too large for a tile through the global sort as a compact list).  Same
@@ -208,6 +260,7 @@ def test_rounds_sorted_in_lds_match_global_sort(gpu, oracle, monkeypatch):
     word text (millions of small groups, later rounds with few groups: the unpacked form), names with a truncation depth,
     a block repeated 12 times (doubling rounds, groups of 12), a text with one 60 000-character run (a group far larger
     than a tile next to small ones), a skewed alphabet (dense active set, groups of every size)."""
+    monkeypatch.setenv("SA_HIP_PERIOD_FINISH", "0")   # long repeats through the rounds here; the periodic-run shortcut has its own test
     from suffixarray_amd import synth
     rng = np.random.default_rng(31)
     words = synth.d2_words(6_000_000)
@@ -288,6 +341,7 @@ def test_group_finisher_matches_global_rounds(gpu, oracle, monkeypatch):
     of every size), a 60 000-character run (one group far larger than a tile), blocks repeated 12 times (groups of 12
     that no bounded number of rounds separates: the finisher must give up and leave them to the doubling rounds), a
     skewed alphabet, near-random text without the tiny-group finisher (pairs), texts that end inside a group."""
+    monkeypatch.setenv("SA_HIP_PERIOD_FINISH", "0")   # long repeats through the rounds here; the periodic-run shortcut has its own test
     from suffixarray_amd import synth
     rng = np.random.default_rng(77)
     words = synth.d2_words(5_000_000)
@@ -341,6 +395,7 @@ def test_build_device64_is_the_libsais64_layout(gpu, oracle, monkeypatch):
     the narrow sort's last pass + the patch of the refined slots (near-random text with tied pairs, word text with
     millions of refined slots through finisher and rounds, a truncated build) or from the widening pass at the end
     (texts too short for the narrow plan, 12-byte-record plan)."""
+    monkeypatch.setenv("SA_HIP_PERIOD_FINISH", "0")   # long repeats through the rounds here; the periodic-run shortcut has its own test
     import torch
     from suffixarray_amd import synth
     runs = [("d1", synth.d1_uniform27(4_500_000), 0, {}, True), ("d1_L12", synth.d1_uniform27(4_500_000), 12, {}, True),

@@ -132,18 +132,31 @@ def test_config3_n1e9_properties(gpu, oracle):
             assert bytes(t[sa[nxt]:sa[nxt] + m]) > p
 
 
-def test_long_repeats_67m_many_doubling_rounds(gpu):
+def test_long_repeats_67m_many_doubling_rounds(gpu, monkeypatch):
     """A 1 MiB random block repeated 64 times: ~24 refinement rounds over 6.7e7 active records each.
     Regression for a lost-LDS-atomic race (bare s_barrier after ds_add on a loop path, see
-    common.hpp sync_lds) that corrupted one per-chunk histogram in about one sort out of twenty."""
+    common.hpp sync_lds) that corrupted one per-chunk histogram in about one sort out of twenty.
+    Then the same text with the periodic-run shortcut (period_finish.hpp): no doubling round at all, the same array."""
     rng = np.random.default_rng(1)
     t = np.tile(rng.integers(97, 123, 1 << 20, dtype=np.uint8), 64)
+    monkeypatch.setenv("SA_HIP_PERIOD_FINISH", "0")
     with gpu.DeviceIndex(t.size, 0) as idx:
         for _ in range(2):
             idx.build(t)
             st = idx.build_stats()
             assert st["doubling_rounds"] >= 20, st
             assert idx.verify() == 0, st
+        slow = idx.sa_u32().copy()
+        slow_ms = st["total_ms"]
+    monkeypatch.setenv("SA_HIP_PERIOD_FINISH", "1")
+    with gpu.DeviceIndex(t.size, 0) as idx:
+        idx.build(t)
+        idx.build_device(idx.text_dev, t.size, 0)
+        st = idx.build_stats()
+        assert st["doubling_rounds"] == 0 and st["period_resolved"] > t.size // 2, st
+        assert idx.verify() == 0, st
+        assert np.array_equal(idx.sa_u32(), slow)
+        print("1 MiB block x 64 (n = 6.7e7): %.1f ms through the doubling rounds, %.1f ms with the periodic-run shortcut" % (slow_ms, st["total_ms"]))
 
 
 def test_beyond_int32_max_3e9_verified(gpu, monkeypatch):

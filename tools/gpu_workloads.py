@@ -18,6 +18,7 @@ def names(n, seed=5):
     return np.frombuffer(bytes(out[:n]), dtype=np.uint8).copy()
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
+ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None
 rng = np.random.default_rng(1)
 cases = [
     ("d1_uniform27", lambda: synth.d1_uniform27(N), 0),
@@ -32,6 +33,8 @@ cases = [
     ("fib_1e7", lambda: synth.fibonacci(10_000_000), 0),
 ]
 for name, gen, L in cases:
+    if ONLY and name not in ONLY:
+        continue
     t = gen()
     with _capi.DeviceIndex(t.size, 0) as idx:
         idx.build(t, L)           # warm-up (allocations)
@@ -40,4 +43,5 @@ for name, gen, L in cases:
         t0 = time.time(); bad = idx.verify(); tv = time.time() - t0
         print("%-18s n=%-11d L=%-3d total %8.2f ms (%6.2f Gchars/s) radix %8.2f ms passes %3d k0=%2d b=%d rounds %d (chunk %d, dbl %d) depth %d active_total %d verify=%d (%.0f ms)" % (
             name, t.size, L, st["total_ms"], t.size / st["total_ms"] / 1e6, st["radix_ms"], st["radix_passes"], st["initial_chars"],
-            st["bits_per_symbol"], st["rounds"], st["chunk_rounds"], st["doubling_rounds"], st["final_depth"], st["active_total"], bad, tv * 1e3), flush=True)
+            st["bits_per_symbol"], st["rounds"], st["chunk_rounds"], st["doubling_rounds"], st["final_depth"], st["active_total"], bad, tv * 1e3),
+            "period_resolved", st.get("period_resolved"), flush=True)
