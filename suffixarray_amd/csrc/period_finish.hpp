@@ -8,7 +8,7 @@
 //
 // Members of a group are kept in ascending text position (every sort is stable and starts from the identity).  If a
 // group's positions are p0, p0 + d, ..., p0 + (m - 1) d and the text is periodic with period d from p0 up to E -- E the
-// first x >= p0 with x + d >= n or T[x] != T[x + d] -- and E >= p0 + (m - 1) d, then ANY two neighbours a = p, b = p + d
+// first x >= p0 with x + d >= n or T[x] != T[x + d] -- and E >= p0 + (m - 2) d, then ANY two neighbours a = p, b = p + d
 // agree on their first E - p characters and differ right there: a has T[E], b has T[E + d] (or has ended).  The outcome
 // is the same for every pair of the group, so the whole group is ordered by ONE comparison: descending positions when
 // b < a (b ended, or T[E + d] < T[E]), ascending otherwise.  No assumption on how d compares with the depth h.
@@ -47,18 +47,35 @@ __global__ __launch_bounds__(256) void per_classify_kernel(const u32* __restrict
         if (j >= (u64)gstart[g] + 2 && aidx[j] - aidx[j - 1] != gd[g]) bad[g] = 1;
     }
 }
-// table[slot] = {d, records of arithmetic groups with that difference} (open addressing; d >= 1)
+// table[slot] = {d, records of arithmetic groups with that difference} (open addressing; d >= 1).  A periodic text has ONE
+// difference for a million groups: the lanes of a wave that hold the same d are combined first (one atomic per distinct d and
+// wave; a million atomics on one word took ~20 ms per call)
 __global__ __launch_bounds__(256) void per_hist_kernel(const u32* __restrict__ gstart, u32 G, const u32* __restrict__ gd,
                                                        const u8* __restrict__ bad, uint2* __restrict__ table) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) {
-        if (bad[g]) continue;
-        const u32 d = gd[g], size = gstart[g + 1] - gstart[g];
-        u32 slot = (d * 0x9E3779B1u) >> 16;
-        for (u32 probe = 0; probe < 64; ++probe) {
-            const u32 old = atomicCAS(&table[slot].x, 0u, d);
-            if (old == 0u || old == d) { atomicAdd(&table[slot].y, size); break; }
-            slot = (slot + 1u) & (PER_TABLE - 1u);
+    const u64 g0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 rounds = ((u64)G + stride - 1) / stride;
+    for (u64 it = 0; it < rounds; ++it) {
+        const u64 g = g0 + it * stride;
+        u32 d = 0, size = 0;
+        if (g < G && !bad[g]) { d = gd[g]; size = gstart[g + 1] - gstart[g]; }
+        u64 todo = __ballot(d != 0);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const u32 dl = __shfl(d, leader);
+            const u64 same = __ballot(d == dl) & todo;
+            u32 sum = (d == dl) ? size : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            if ((int)(threadIdx.x & 63) == leader) {
+                u32 slot = (dl * 0x9E3779B1u) >> 16;
+                for (u32 probe = 0; probe < 64; ++probe) {
+                    const u32 old = atomicCAS(&table[slot].x, 0u, dl);
+                    if (old == 0u || old == dl) { atomicAdd(&table[slot].y, sum); break; }
+                    slot = (slot + 1u) & (PER_TABLE - 1u);
+                }
+            }
+            todo &= ~same;
         }
     }
 }
@@ -162,7 +179,8 @@ __global__ __launch_bounds__(256) void per_decide_kernel(PerArgs a) {
                 }
             }
             if (E == ~0ull) { const u32 c = a.carry[t]; E = (c == 0xFFFFFFFFu) ? a.n : (u64)c; }
-            if (E >= plast && E < a.n) dec = ((E + a.d >= a.n) || a.text[E + a.d] < a.text[E]) ? 2 : 1;
+            // every neighbouring pair (p_j, p_j + d), j <= m - 2, must meet its first mismatch at the same E: E >= p_{m-2} = plast - d
+            if (E + a.d >= plast && E < a.n) dec = ((E + a.d >= a.n) || a.text[E + a.d] < a.text[E]) ? 2 : 1;
         }
         if (lane == 0) a.dec[g] = dec;
     }
