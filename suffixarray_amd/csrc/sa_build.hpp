@@ -998,7 +998,7 @@ struct Builder {
     CodeMap qmap;
     int q_b = 0, q_k0 = 0, q_dbits = 0;
     bool dir_ready = false;   // the directory in qdir belongs to qkeys
-    int sector_search = 1;        // SA_HIP_SECTOR_SEARCH: interpolated scan inside a directory bucket (sa_query.hpp): 1 = 64-byte windows, 2 = 32-byte windows, 0 = binary search
+    int sector_search = 2;        // SA_HIP_SECTOR_SEARCH: interpolated scan inside a directory bucket (sa_query.hpp): 1 = 64-byte windows, 2 = 32-byte windows, 0 = binary search
 
     // Characters in the initial key.  Enough that, for an i.i.d. text with this byte
     // distribution, about 2 % of the suffixes still share their key (collision probability
@@ -1255,10 +1255,11 @@ struct Builder {
 
     // Bucket directory over the top q_dbits bits of the sorted keys (qkeys must be set), built in two
     // levels: a 2^14-bucket directory by full binary searches, then the fine one inside its buckets.
-    // Default q_dbits = log2(n) - 4, at most 27 (about 16 slots per bucket = one 64-byte sector of narrow keys: the
-    // key search of a query stays inside one or two sectors; at n = 1e9, per 1M-query batch, 24 / 25 / 26 / 27 / 28
-    // bits: 0.169 / 0.148 / 0.125 / 0.109 / 0.101 ms, for +0.2 ms of build per bit -- the directory entries are
-    // written by the flags pass, 4 bytes each, 268 MB at 26 bits); SA_HIP_DIR_BITS overrides.
+    // Default q_dbits = log2(n) - 3, at most 27 (round 3: about 8 slots per bucket = one 32-byte window of narrow keys, the
+    // granule random reads are served in, sa_query.hpp; at n = 1e9 with 32-byte windows, per 1M-query batch, 25 / 26 / 27 / 28
+    // bits: 0.108 / 0.090 / 0.082 / 0.083 ms, build 21.0 / 21.26 / 21.5 / 27.1 ms on the same box -- the directory entries
+    // are written by the flags pass, 4 bytes each, 537 MB at 27 bits; at 28 bits the 1 GB of scattered directory stores cost
+    // more than the batch gains); SA_HIP_DIR_BITS overrides.
     // qdir layout: fine directory u32[nb] | coarse directory u32[ncb] (two-level build only) | gap queue
     static int dir_coarse_bits(int d) { return d > 16 ? 14 : 0; }
     static size_t dir_gap_offset(u64 nb) { return (((size_t)nb + (1u << 14) + 1) * 4 + 15) & ~(size_t)15; }
@@ -1268,7 +1269,7 @@ struct Builder {
     int directory_layout(u64 count) {
         int lg = 0;
         while ((1ull << lg) < count) ++lg;
-        int d = lg - 4;
+        int d = lg - 3;
         if (d < 8) d = 8;
         if (d > 27) d = 27;
         if (const char* e = diag_env("SA_HIP_DIR_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 28) d = v; }

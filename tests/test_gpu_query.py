@@ -538,8 +538,8 @@ def test_narrow_key_array_matches_wide_key_array(gpu, oracle, monkeypatch):
 
 
 def test_sector_search_matches_binary_search(gpu, oracle, monkeypatch):
-    """Inside a directory bucket the key search is an interpolated scan of whole 64-byte sectors (sa_query.hpp:
-    sector_bound; default) instead of a binary search (SA_HIP_SECTOR_SEARCH=0): identical ranges, equal to the oracle's
+    """Inside a directory bucket the key search is an interpolated scan of 32-byte windows (sa_query.hpp: sector_bound;
+    default, SA_HIP_SECTOR_SEARCH=2) or whole 64-byte sectors (=1) instead of a binary search (=0): identical ranges, equal to the oracle's
     (engine.c:869-918), for narrow (u32) and wide (u64) key arrays, adopted indexes (keys gathered from the text), a
     skewed alphabet (buckets of very different sizes, long runs of equal keys: the estimate is far off and the scan falls
     back to bisection), word text (equal keys in the thousands), texts shorter than a sector, truncated indexes."""
@@ -559,7 +559,7 @@ def test_sector_search_matches_binary_search(gpu, oracle, monkeypatch):
         pats += [bytes([c]) for c in np.unique(t)[:8]] + [bytes(t[p:p + m]) for p in (0, max(t.size - 9, 0)) for m in (1, 2, 3, 8, 9, 16)]
         got = {}
         sa = None
-        for mode in ("1", "0"):
+        for mode in ("2", "1", "0"):
             monkeypatch.setenv("SA_HIP_SECTOR_SEARCH", mode)
             with gpu.DeviceIndex(t.size, 0) as idx:
                 idx.build(t, L)
