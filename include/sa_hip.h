@@ -325,6 +325,16 @@ int sa_hip_init_suffix_array_byte_idxs(sa_hip_SuffixArray_struct* sa, uint32_t m
                                        uint64_t global_byte_end_idx, uint32_t n);
 void sa_hip_free_suffix_array(sa_hip_SuffixArray_struct* sa);
 
+/* replaces write_suffix_array (engine.h:142-146, engine.c:1112-1138) and read_suffix_array (declared at engine.h:141, never
+ * defined in the reference): the reference's own file layout {u64 global_byte_start_idx, u64 global_byte_end_idx,
+ * u32 max_suffix_length, u32 n, u32 suffix_array[n]}, so that an index file of either side can be read by the other.
+ * is_quoted_filename (may be NULL) receives an empty bit buffer {u32 capacity = 0} (engine.c:1098-1101): this library
+ * keeps row tables instead of per-character quoted bits.  The reader mallocs suffix_array (sa_hip_free_suffix_array) and
+ * refuses entries >= n.  Note for CSV mode: the reference stores FILE byte offsets in the array (engine.c:648-651), this
+ * library positions of the extracted column; SuffixArray.save / load of the Python class keep the row tables beside it. */
+int sa_hip_write_suffix_array(const sa_hip_SuffixArray_struct* sa, const char* sa_filename, const char* is_quoted_filename);
+int sa_hip_read_suffix_array(sa_hip_SuffixArray_struct* sa, const char* sa_filename);
+
 /* ---- instrumentation ---------------------------------------------------------------------- */
 
 /* Per-build statistics of the last build on this handle (roofline accounting). */

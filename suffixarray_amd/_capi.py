@@ -30,7 +30,7 @@ EXPORTS = [
     "sa_hip_csv_index_destroy", "sa_hip_csv_index_handle", "sa_hip_csv_index_num_rows", "sa_hip_csv_index_num_columns",
     "sa_hip_csv_index_column_index", "sa_hip_csv_index_column_name", "sa_hip_csv_index_row_tables",
     "sa_hip_get_substring_positions_file", "sa_hip_get_matching_records_file", "sa_hip_get_matching_records", "sa_hip_free_records",
-    "sa_hip_init_suffix_array_byte_idxs", "sa_hip_free_suffix_array",
+    "sa_hip_init_suffix_array_byte_idxs", "sa_hip_free_suffix_array", "sa_hip_write_suffix_array", "sa_hip_read_suffix_array",
     "sa_hip_comm_unique_id", "sa_hip_comm_create", "sa_hip_comm_destroy", "sa_hip_comm_rank", "sa_hip_comm_size",
     "sa_hip_comm_replicate_index", "sa_hip_comm_allgather_ranges",
     "sa_hip_index_replica_layout", "sa_hip_index_replica_buffers", "sa_hip_index_replica_reserve", "sa_hip_index_replica_commit",
@@ -259,6 +259,10 @@ def lib():
     L.sa_hip_init_suffix_array_byte_idxs.argtypes = [C.POINTER(SuffixArrayStruct), u32, u64, u64, u32]
     L.sa_hip_free_suffix_array.restype = None
     L.sa_hip_free_suffix_array.argtypes = [C.POINTER(SuffixArrayStruct)]
+    L.sa_hip_write_suffix_array.restype = C.c_int
+    L.sa_hip_write_suffix_array.argtypes = [C.POINTER(SuffixArrayStruct), C.c_char_p, C.c_char_p]
+    L.sa_hip_read_suffix_array.restype = C.c_int
+    L.sa_hip_read_suffix_array.argtypes = [C.POINTER(SuffixArrayStruct), C.c_char_p]
     L.sa_hip_sort_pairs.restype = C.c_int
     L.sa_hip_sort_pairs.argtypes = [vp, vp, u64, C.c_int, C.c_int, C.c_int]
     L.sa_hip_synth_uniform27.restype = None

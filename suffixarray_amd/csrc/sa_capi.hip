@@ -1186,6 +1186,50 @@ void sa_hip_free_suffix_array(sa_hip_SuffixArray_struct* s) {
     s->suffix_array = nullptr;
 }
 
+// ---- the reference's on-disk layout (engine.c:1098-1165) ----------------------------------------------------------------
+
+int sa_hip_write_suffix_array(const sa_hip_SuffixArray_struct* s, const char* sa_filename, const char* is_quoted_filename) {
+    if (!s || !sa_filename || (!s->suffix_array && s->n)) return fail(SA_HIP_EINVAL, "sa_hip_write_suffix_array: NULL argument");
+    FILE* f = fopen(sa_filename, "wb");
+    if (!f) return fail(SA_HIP_EINVAL, "sa_hip_write_suffix_array: cannot open file", sa_filename);
+    // engine.c:1123-1128: {u64 global_byte_start_idx, u64 global_byte_end_idx, u32 max_suffix_length, u32 n, u32 suffix_array[n]}
+    bool ok = fwrite(&s->global_byte_start_idx, 8, 1, f) == 1 && fwrite(&s->global_byte_end_idx, 8, 1, f) == 1 &&
+              fwrite(&s->max_suffix_length, 4, 1, f) == 1 && fwrite(&s->n, 4, 1, f) == 1 &&
+              (s->n == 0 || fwrite(s->suffix_array, 4, s->n, f) == s->n);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return fail(SA_HIP_EINVAL, "sa_hip_write_suffix_array: short write", sa_filename);
+    if (is_quoted_filename) {
+        // engine.c:1098-1101 write_buffer_bit: {u32 capacity, bytes}; this library keeps no quoted bits (sa_hip.h): capacity 0
+        FILE* q = fopen(is_quoted_filename, "wb");
+        if (!q) return fail(SA_HIP_EINVAL, "sa_hip_write_suffix_array: cannot open file", is_quoted_filename);
+        const uint32_t cap = 0;
+        ok = fwrite(&cap, 4, 1, q) == 1;
+        ok = (fclose(q) == 0) && ok;
+        if (!ok) return fail(SA_HIP_EINVAL, "sa_hip_write_suffix_array: short write", is_quoted_filename);
+    }
+    return 0;
+}
+
+int sa_hip_read_suffix_array(sa_hip_SuffixArray_struct* s, const char* sa_filename) {
+    if (!s || !sa_filename) return fail(SA_HIP_EINVAL, "sa_hip_read_suffix_array: NULL argument");
+    memset(s, 0, sizeof *s);
+    FILE* f = fopen(sa_filename, "rb");
+    if (!f) return fail(SA_HIP_EINVAL, "sa_hip_read_suffix_array: cannot open file", sa_filename);
+    int rc = 0;
+    if (fread(&s->global_byte_start_idx, 8, 1, f) != 1 || fread(&s->global_byte_end_idx, 8, 1, f) != 1 ||
+        fread(&s->max_suffix_length, 4, 1, f) != 1 || fread(&s->n, 4, 1, f) != 1)
+        rc = fail(SA_HIP_EINVAL, "sa_hip_read_suffix_array: truncated header", sa_filename);
+    if (!rc) {
+        s->suffix_array = static_cast<uint32_t*>(malloc((size_t)(s->n ? s->n : 1) * 4));
+        if (!s->suffix_array) rc = fail(SA_HIP_ENOMEM, "sa_hip_read_suffix_array: out of host memory");
+        else if (s->n && fread(s->suffix_array, 4, s->n, f) != s->n) rc = fail(SA_HIP_EINVAL, "sa_hip_read_suffix_array: truncated array", sa_filename);
+        if (!rc) for (uint32_t i = 0; i < s->n; ++i) if (s->suffix_array[i] >= s->n) { rc = fail(SA_HIP_EINVAL, "sa_hip_read_suffix_array: entry >= n", sa_filename); break; }
+    }
+    fclose(f);
+    if (rc) { free(s->suffix_array); memset(s, 0, sizeof *s); }
+    return rc;
+}
+
 // ---- libsais-call-compatible wrappers --------------------------------------------------------------
 // Host pointers in, host suffix array out.  One process-level workspace serves all of them (host_io.hpp): a cached
 // index handle whose device buffers are allocated once and grow on demand, and a ring of pinned slabs for both legs

@@ -129,18 +129,26 @@ cdef class SuffixArray:
     cdef object _row_starts
     cdef public list columns
     cdef public str csv_filename
+    cdef list _parts                 # documents beyond one index's 2^32 - 2 bytes: one SuffixArray per partition
+    cdef uint64_t _partition_bytes
 
     def __cinit__(self):
         self._idx = NULL
         self._csv = NULL
 
     def __init__(self, documents=None, csv_file=None, search_column=None, max_suffix_length: int = 64,
-                 device: int = 0):
+                 device: int = 0, partition_bytes=None):
+        """partition_bytes: documents whose joined text exceeds it are indexed as several partitions of whole documents,
+        each a device index of its own, queried one after the other until k records are found -- the reference's scheme
+        for large inputs (2 GiB partitions, suffix_array.pyx:148-180, 221-247), cut at document boundaries here so that no
+        match is lost at a cut.  Default: 4e9 bytes (one index holds up to 2^32 - 2)."""
         if max_suffix_length is None or int(max_suffix_length) < 1:
             raise ValueError("max_suffix_length must be >= 1")
         self._L = <uint32_t>int(max_suffix_length)
         self.device = int(device)
         self._mode = ""
+        self._parts = None
+        self._partition_bytes = 4_000_000_000 if partition_bytes is None else max(1, min(int(partition_bytes), 4_000_000_000))
         if documents is not None and csv_file is not None:
             raise ValueError("pass either documents= or csv_file=, not both")
         if documents is not None:
@@ -154,6 +162,10 @@ cdef class SuffixArray:
         self._release()
 
     cdef _release(self):
+        if self._parts is not None:
+            for p in self._parts:
+                p.close()
+            self._parts = None
         if self._csv != NULL:
             sa_hip_csv_index_destroy(self._csv)   # owns the device index
             self._csv = NULL
@@ -218,6 +230,24 @@ cdef class SuffixArray:
         self._documents = documents
         encoded = [d.encode("utf-8") for d in documents]
         lens = np.fromiter((len(e) for e in encoded), dtype=np.int64, count=len(encoded))
+        if len(encoded) and int(lens.sum()) + len(encoded) - 1 > self._partition_bytes:
+            # several partitions of whole documents (pyx:148-180 cuts the TEXT every 2 GiB and loses matches at the cuts)
+            self._release()
+            self._parts = []
+            lo = 0
+            acc = 0
+            for i in range(len(encoded)):
+                add = int(lens[i]) + (1 if i > lo else 0)
+                if i > lo and acc + add > self._partition_bytes:
+                    self._parts.append(SuffixArray(documents=documents[lo:i], max_suffix_length=self._L, device=self.device,
+                                                   partition_bytes=4_000_000_000))
+                    lo, acc, add = i, 0, int(lens[i])
+                if add > 4_000_000_000:
+                    raise ValueError("a single document exceeds 2^32 - 2 bytes (one index per partition)")
+                acc += add
+            self._parts.append(SuffixArray(documents=documents[lo:], max_suffix_length=self._L, device=self.device, partition_bytes=4_000_000_000))
+            self._mode = "partitioned"
+            return
         starts = np.concatenate([[0], np.cumsum(lens + 1)[:-1]]).astype(np.uint64) if len(encoded) else np.zeros(0, np.uint64)
         self._build_documents(ascii_lower(b"\n".join(encoded)), starts, None)
         self._mode = "documents"
@@ -248,6 +278,8 @@ cdef class SuffixArray:
     # -- query --------------------------------------------------------------------------------------------------------
     def query_ranges(self, substrings):
         """Batched get_substring_positions (engine.c:869-918 per element): structured (first, second)."""
+        if self._mode == "partitioned":
+            raise RuntimeError("a partitioned index has one suffix array per partition: use .partitions[i].query_ranges")
         if self._idx == NULL:
             raise RuntimeError("index not built")
         pats = [ascii_lower(s.encode("utf-8")) if isinstance(s, str) else ascii_lower(bytes(s)) for s in substrings]
@@ -290,6 +322,14 @@ cdef class SuffixArray:
         """pyx:209-267: records containing `substring` (case-insensitive ASCII), at most k."""
         if substring == "" or k <= 0:
             return []
+        if self._mode == "partitioned":
+            # pyx:221-247: the partitions one after the other until k records are found
+            out = []
+            for p in self._parts:
+                out += p.query_records(substring, k - len(out))
+                if len(out) >= k:
+                    break
+            return out
         if self._idx == NULL:
             raise RuntimeError("index not built")
         cdef bytes pat = ascii_lower(substring.encode("utf-8") if isinstance(substring, str) else bytes(substring))
@@ -333,6 +373,12 @@ cdef class SuffixArray:
         res = [[] for _ in substrings]
         if not live or k <= 0:
             return res
+        if self._mode == "partitioned":
+            for p in self._parts:     # one batched call per partition
+                for i, r in enumerate(p.query_records_batch(substrings, k)):
+                    if len(res[i]) < k:
+                        res[i] += r[:k - len(res[i])]
+            return res
         if self._idx == NULL:
             raise RuntimeError("index not built")
         pats = [ascii_lower(substrings[i].encode("utf-8")) if isinstance(substrings[i], str) else ascii_lower(bytes(substrings[i])) for i in live]
@@ -362,7 +408,20 @@ cdef class SuffixArray:
 
     # -- persistence (SURVEY.md 8(f)-3; the reference's save / load is half-built: engine.c:1098-1165, commented-out
     #    pyx:310-423).  Versioned directory: meta.json + raw little-endian arrays; load() adopts them, no rebuild. -------
+    @property
+    def partitions(self):
+        """The per-partition indexes of a partitioned documents index (else [self])."""
+        return list(self._parts) if self._parts is not None else [self]
+
     def save(self, directory: str):
+        if self._mode == "partitioned":
+            _os.makedirs(directory, exist_ok=True)
+            for i, p in enumerate(self._parts):
+                p.save(_os.path.join(directory, "part%04d" % i))
+            with open(_os.path.join(directory, "meta.json"), "w") as f:
+                _json.dump({"format": "suffixarray_amd", "version": FORMAT_VERSION, "mode": "partitioned", "parts": len(self._parts),
+                            "max_suffix_length": int(self._L)}, f)
+            return
         if self._idx == NULL:
             raise RuntimeError("index not built")
         _os.makedirs(directory, exist_ok=True)
@@ -410,6 +469,11 @@ cdef class SuffixArray:
         if meta.get("format") != "suffixarray_amd" or meta.get("version") != FORMAT_VERSION:
             raise ValueError("not a suffixarray_amd index of a supported version")
         cdef SuffixArray self = cls(max_suffix_length=meta["max_suffix_length"], device=device)
+        if meta.get("mode") == "partitioned":
+            self._parts = [cls.load(_os.path.join(directory, "part%04d" % i), device) for i in range(int(meta["parts"]))]
+            self._documents = [d for p in self._parts for d in (<SuffixArray>p)._documents]
+            self._mode = "partitioned"
+            return self
         text = np.fromfile(_os.path.join(directory, "text.u8"), dtype=np.uint8)
         sa = np.fromfile(_os.path.join(directory, "sa.u32"), dtype=np.uint32)
         if text.size != meta["n"] or sa.size != meta["n"]:

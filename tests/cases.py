@@ -1,5 +1,6 @@
 """Shared input cases for the parity tests (same seeds on CPU and GPU)."""
 import numpy as np
+import pytest
 
 from suffixarray_amd import synth
 
@@ -47,3 +48,30 @@ def query_patterns(text, count, rng, maxlen=40):
             pats.append(bytes(rng.integers(97, 123, m, dtype=np.uint8)))
     pats += [b"", b"a", b"zzzzzzzz", bytes([255]) * 3, bytes([1]), bytes(text[-5:]), bytes(text[-1:]), bytes(text[:7])]
     return pats
+
+
+def check_partitioned(SuffixArray, tmp_path):
+    """documents cut into partitions of whole documents (the reference's scheme for inputs beyond one index, pyx:148-180,
+    221-247): the same records as one index over everything, k honoured across partitions, save / load."""
+    rng = np.random.default_rng(17)
+    words = ["alpha", "beta", "gamma", "delta", "Milk", "store", "fox", "lazy dog", "quick", "brown"]
+    docs = [" ".join(words[j] for j in rng.integers(0, len(words), rng.integers(2, 9))) + (" #%d" % i) for i in range(120)]
+    one = SuffixArray(documents=docs, max_suffix_length=32)
+    part = SuffixArray(documents=docs, max_suffix_length=32, partition_bytes=700)
+    assert len(part.partitions) >= 5 and len(one.partitions) == 1
+    for q in ("milk", "lazy dog", "FOX", "#7", "zzz", "a", "alpha beta"):
+        exp = [d for d in docs if q.lower() in d.lower()]
+        assert sorted(one.query_records(q, k=10**6)) == sorted(exp)
+        assert sorted(part.query_records(q, k=10**6)) == sorted(exp), q
+        few = part.query_records(q, k=3)
+        assert len(few) == min(3, len(exp)) and all(r in exp for r in few)
+    got = part.query_records_batch(["milk", "", "delta", "zzz"], k=5)
+    assert got[1] == [] and got[3] == [] and len(got[0]) == min(5, sum("milk" in d.lower() for d in docs)) and all("delta" in r.lower() for r in got[2])
+    with pytest.raises(RuntimeError):
+        part.query_ranges(["milk"])
+    part.save(str(tmp_path / "parts"))
+    back = SuffixArray.load(str(tmp_path / "parts"))
+    assert len(back.partitions) == len(part.partitions)
+    assert sorted(back.query_records("quick", k=10**6)) == sorted(d for d in docs if "quick" in d.lower())
+    for x in (one, part, back):
+        x.close()

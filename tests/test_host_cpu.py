@@ -109,6 +109,7 @@ def test_config1_readme_on_the_opt_in_host_path(capi, oracle, monkeypatch, tmp_p
             assert np.array_equal(capi.libsais(t), sa.astype(np.int32)) and np.array_equal(capi.libsais64(t), sa.astype(np.int64))
     with pytest.raises(capi.SaHipError):
         capi.DeviceIndex((1 << 24) + 1, 0)           # the host path is small on purpose
+    cases.check_partitioned(SuffixArray, tmp_path)
     # CSV mode end to end
     p = tmp_path / "c.csv"
     p.write_text('id,company_name,country\n1,Netflix,US\n2,"Acme, Inc.",US\n3,netflix studios,US\n')
@@ -136,6 +137,34 @@ def test_host_code_under_sanitizers(tmp_path, flags):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "clean" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_reference_file_layout_roundtrip(capi, tmp_path):
+    """sa_hip_write_suffix_array / sa_hip_read_suffix_array use the reference's own layout (engine.c:1123-1128:
+    {u64 start, u64 end, u32 max_suffix_length, u32 n, u32 SA[n]}; the bit-buffer file {u32 capacity, bytes}, engine.c:1098-1101)."""
+    import ctypes as C
+    sa = np.array([5, 3, 1, 0, 4, 2], dtype=np.uint32)
+    st = capi.SuffixArrayStruct()
+    st.suffix_array = sa.ctypes.data
+    st.global_byte_start_idx, st.global_byte_end_idx, st.max_suffix_length, st.n = 7, 1234567890123, 32, sa.size
+    f, q = str(tmp_path / "sa.bin"), str(tmp_path / "q.bin")
+    capi.check(capi.lib().sa_hip_write_suffix_array(C.byref(st), f.encode(), q.encode()))
+    raw = open(f, "rb").read()
+    assert len(raw) == 24 + 4 * sa.size
+    assert np.frombuffer(raw[:16], "<u8").tolist() == [7, 1234567890123] and np.frombuffer(raw[16:24], "<u4").tolist() == [32, 6]
+    assert np.array_equal(np.frombuffer(raw[24:], "<u4"), sa)
+    assert open(q, "rb").read() == b"\0\0\0\0"
+    back = capi.SuffixArrayStruct()
+    capi.check(capi.lib().sa_hip_read_suffix_array(C.byref(back), f.encode()))
+    assert (back.n, back.max_suffix_length, back.global_byte_start_idx, back.global_byte_end_idx) == (6, 32, 7, 1234567890123)
+    assert np.ctypeslib.as_array(C.cast(back.suffix_array, C.POINTER(C.c_uint32)), (6,)).tolist() == sa.tolist()
+    capi.lib().sa_hip_free_suffix_array(C.byref(back))
+    open(f, "wb").write(raw[:-3])
+    assert capi.lib().sa_hip_read_suffix_array(C.byref(back), f.encode()) == -1 and not back.suffix_array
+    bad = bytearray(raw); bad[24:28] = (99).to_bytes(4, "little")
+    open(f, "wb").write(bytes(bad))
+    assert capi.lib().sa_hip_read_suffix_array(C.byref(back), f.encode()) == -1
+    assert capi.lib().sa_hip_read_suffix_array(C.byref(back), str(tmp_path / "missing").encode()) == -1
 
 
 def test_synth_d1_matches_definition(capi):
