@@ -484,7 +484,7 @@ __device__ __forceinline__ void shl_or_inplace(u32& acc, u32 x, int s) {
 template <bool FULL, int BLOCK, bool EXT>
 __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 tile, const u32 chunk,
                                               const u32 tile_n, u32* s_keys, u32* s_whist, u32* s_gdelta, u32* s_wsum,
-                                              u8* s_code, const u8* s_map) {
+                                              u8* s_code, const u8* s_map, u16* s_ext) {
     constexpr int WAVES = BLOCK / WAVE;
     constexpr int ITEMS = TEXT_ITEMS;
     constexpr u32 TILE = BLOCK * ITEMS;
@@ -604,7 +604,10 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
     for (int j = 0; j < ITEMS; ++j) {
         const u32 d = rd[j] >> 16;
         pos[j] = wh[d] + (rd[j] & 0xFFFFu);
-        if (FULL || (woff + j * WAVE) < tile_n) { s_keys[pos[j]] = key[j]; s_dig[pos[j]] = (u8)d; }
+        if (FULL || (woff + j * WAVE) < tile_n) {
+            s_keys[pos[j]] = key[j]; s_dig[pos[j]] = (u8)d;
+            if (EXT) s_ext[pos[j]] = (u16)ext[j];   // the low 16 key bits beside the upper 32: one staging round for both
+        }
     }
     __syncthreads();
 
@@ -629,22 +632,10 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
         if (FULL || p < tile_n) {
             gidx[k] = s_gdelta[s_dig[p]] + p;
             a.keys_out32[gidx[k]] = s_keys[p];
+            if (EXT) a.ext_out16[gidx[k]] = s_ext[p];
         }
     }
     __syncthreads();
-    if (EXT) {   // the low 16 key bits take the same route (the key array's LDS as u16)
-        u16* s_ext = reinterpret_cast<u16*>(s_keys);
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j)
-            if (FULL || (woff + j * WAVE) < tile_n) s_ext[pos[j]] = (u16)ext[j];
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {
-            const u32 p = k * BLOCK + tid;
-            if (FULL || p < tile_n) a.ext_out16[gidx[k]] = s_ext[p];
-        }
-        __syncthreads();
-    }
     u32* s_vals = s_keys;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j)
@@ -667,6 +658,7 @@ __global__ __launch_bounds__(BLOCK, (TEXT_ITEMS > 16 || EXT) ? 4 : 6) void text_
     __shared__ u32 s_gdelta[RADIX];
     __shared__ u32 s_wsum[RADIX / WAVE];
     __shared__ __attribute__((aligned(16))) u8 s_code[TILE + TEXT_HALO];   // codes, later the top digit per sorted slot
+    __shared__ u16 s_ext[EXT ? TILE : 2];
     __shared__ u8 s_map[256];
     __shared__ u32 s_tile;
     __shared__ u32 s_chunk;
@@ -694,9 +686,9 @@ __global__ __launch_bounds__(BLOCK, (TEXT_ITEMS > 16 || EXT) ? 4 : 6) void text_
     const u32 chunk = s_chunk;
     const u64 rest = a.n - (u64)tile * TILE;
     if (rest >= (u64)TILE)
-        text_top_tile<true, BLOCK, EXT>(a, tile, chunk, TILE, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
+        text_top_tile<true, BLOCK, EXT>(a, tile, chunk, TILE, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map, s_ext);
     else
-        text_top_tile<false, BLOCK, EXT>(a, tile, chunk, (u32)rest, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map);
+        text_top_tile<false, BLOCK, EXT>(a, tile, chunk, (u32)rest, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map, s_ext);
 }
 
 // ---- pass 0 of the plain LSD sort straight from the text ---------------------------------------------------
