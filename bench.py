@@ -12,9 +12,10 @@ resident in HBM).  `value` = N / (build + widen time): every byte config 3 names
 
 N > 1 (BASELINE config 4: "1 GB text, 10M-query batch sharded across 8 GPUs, SA replicated via RCCL, hits
 gathered"; launched by torch.distributed.run, one rank per GPU): construction stays single-GPU -- rank 0 builds
-ONCE, text + SA reach the other GPUs by one RCCL broadcast per tensor (timed, `broadcast_ms`), every rank adopts
-the replica; a "step" = ONE global batch of --queries-global patterns (the same on every rank) split into
-contiguous slices, searched with no data-path collective, 8-byte ranges all-gathered (device resident).
+ONCE, its query structures (text, SA, key array, directory) reach the other GPUs by one RCCL broadcast per buffer
+straight into buffers the replicas have reserved (timed, `replicate_ms`; nothing is rebuilt there); a "step" = ONE global
+batch of --queries-global patterns (the same on every rank) split into contiguous slices, searched chunk by chunk with no
+data-path collective while the 8-byte ranges of the previous chunk are gathered (--dist-mode all_gather | gather_to_root).
 `value` = global queries/s (strong scaling); the build's chars/s is reported un-multiplied beside it.
 Prints ONE JSON line on rank 0.
 """
