@@ -117,7 +117,7 @@ __device__ __forceinline__ void fin_wave_rank(const u64 (&key)[ITEMS], int shift
 constexpr u32 FIN_COUNT_MAX = 96;   // 0 / 48 / 96 / 160: words 1e8 11.5 / 11.0 / 10.8 / 10.9 ms
 constexpr int FIN_RADIX_CHARS = 0;
 
-__global__ __launch_bounds__(FIN_BLOCK) void group_finish_kernel(FinArgs a, CodeMap map) {
+__global__ __launch_bounds__(FIN_BLOCK, FIN_BLOCK == 512 ? 4 : 2) void group_finish_kernel(FinArgs a, CodeMap map) {
     constexpr int WAVES = FIN_BLOCK / WAVE;
     constexpr int ITEMS = FIN_ITEMS;
     constexpr u32 CAP = FIN_CAP;
@@ -155,6 +155,8 @@ __global__ __launch_bounds__(FIN_BLOCK) void group_finish_kernel(FinArgs a, Code
 
     u32 h = a.h0, rounds = 0, stall = 0;
     u32 dbg_radix = 0, dbg_slots_r = 0, dbg_slots_c = 0, dbg_act = 0;
+    // SA_HIP_DEBUG_ROUNDS=1: cycles of thread 0 per phase (fetch + keys / counting sort / radix sort / regroup), totals[8..11]
+    long long t_fetch = 0, t_count = 0, t_radix = 0, t_regroup = 0, t_mark = a.debug ? clock64() : 0;
     u32* wh = s_whist + wave * RADIX;
     while (true) {
         const u32 A = s_A, G = s_G;
@@ -195,6 +197,16 @@ __global__ __launch_bounds__(FIN_BLOCK) void group_finish_kernel(FinArgs a, Code
 
         // 1. keys: (group << cbits | next kc characters) above the record's compact index
         u64 key[ITEMS];
+        u64 wtext[ITEMS];   // all text fetches of a lane in flight together (inactive rows read the text's first word: cached)
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            wtext[j] = 0;
+            if (j < R) {   // uniform
+                const u32 q = woff + j * WAVE;
+                const u64 start = (q < A) ? (u64)s_idx[q] + h : 0ull;
+                __builtin_memcpy(&wtext[j], a.text + start, 8);      // the text is zero padded: in bounds
+            }
+        }
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             key[j] = ~0ull;   // padding sorts last in every pass and stays behind the records (stable)
@@ -203,8 +215,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void group_finish_kernel(FinArgs a, Code
                 if (q < A) {
                     const u64 start = (u64)s_idx[q] + h;             // <= n: the group shares h real characters
                     const u64 avail = a.n - start;
-                    u64 w;
-                    __builtin_memcpy(&w, a.text + start, 8);         // the text is zero padded: in bounds
+                    const u64 w = wtext[j];
                     u64 chars = 0;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
@@ -218,6 +229,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void group_finish_kernel(FinArgs a, Code
                 }
             }
         }
+        if (a.debug) { const long long t = clock64(); t_fetch += t - t_mark; t_mark = t; }
         if (counting) {
             // 2a. every group is small: a record's place inside its group = the members with a smaller key (the keys are
             //     distinct: they end in the compact index, which also makes the order stable)
@@ -296,6 +308,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void group_finish_kernel(FinArgs a, Code
                 }
             }
         }
+        if (a.debug) { const long long t = clock64(); if (counting) t_count += t - t_mark; else t_radix += t - t_mark; t_mark = t; }
         // 3. new groups, finals, compaction of what is still tied (row = the 64 records of one (wave, j))
         u32 r_idx[ITEMS], r_pos[ITEMS];
         u64 m_act[ITEMS], m_head[ITEMS];
@@ -359,20 +372,45 @@ __global__ __launch_bounds__(FIN_BLOCK) void group_finish_kernel(FinArgs a, Code
         __syncthreads();
         h += (u32)kc;
         ++rounds;
+        if (a.debug) { const long long t = clock64(); t_regroup += t - t_mark; t_mark = t; }
     }
     __syncthreads();   // s_fail complete; the finals of every lane have reached memory (workgroup scope)
     u32 resolved = 0;
-    for (u32 p = tid; p < cnt; p += FIN_BLOCK) {
-        const u32 og = a.gid[begin + p] - gid0;
-        const u8 f = a.res_fin[begin + p];
-        const bool ok = !((s_fail[og >> 5] >> (og & 31)) & 1u) && f != 0;
-        if (ok) {
-            const u32 slot = a.apos[begin + p];
-            a.sa[slot] = a.res_idx[begin + p];
-            if (f & 2) a.gflags[slot] = 1;
-            ++resolved;
+    {
+        constexpr int HALF = ITEMS / 2;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            u32 ogv[HALF], slotv[HALF], idxv[HALF];
+            u8 fv[HALF];
+#pragma unroll
+            // (a loop with a run-time trip count and loads under `if` serialises the memory latencies of its iterations: the
+            //  loads of four records of a thread are issued first, with clamped indices, then used.  Round 3, SA_HIP_DEBUG_ROUNDS=1:
+            //  the text fetches and this write-out were 55 % of a tile's time.  Doing the same to the tile load at the top takes the
+            //  kernel from 123 to 175 VGPRs -- one workgroup per CU -- so that loop stays as it is.)
+            for (int it = 0; it < HALF; ++it) {
+                const u32 p = (u32)tid + (u32)(half * HALF + it) * FIN_BLOCK;
+                const u32 pc = p < cnt ? p : cnt - 1;
+                ogv[it] = a.gid[begin + pc] - gid0;
+                fv[it] = a.res_fin[begin + pc];
+                slotv[it] = a.apos[begin + pc];
+                idxv[it] = a.res_idx[begin + pc];
+            }
+#pragma unroll
+            for (int it = 0; it < HALF; ++it) {
+                const u32 p = (u32)tid + (u32)(half * HALF + it) * FIN_BLOCK;
+                if (p < cnt) {
+                    const u32 og = ogv[it];
+                    const u8 f = fv[it];
+                    const bool ok = !((s_fail[og >> 5] >> (og & 31)) & 1u) && f != 0;
+                    if (ok) {
+                        a.sa[slotv[it]] = idxv[it];
+                        if (f & 2) a.gflags[slotv[it]] = 1;
+                        ++resolved;
+                    }
+                    a.done[begin + p] = ok ? (u8)1 : (u8)0;
+                }
+            }
         }
-        a.done[begin + p] = ok ? (u8)1 : (u8)0;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) resolved += __shfl_down(resolved, o);
@@ -383,6 +421,9 @@ __global__ __launch_bounds__(FIN_BLOCK) void group_finish_kernel(FinArgs a, Code
             atomicAdd(&a.totals[2], (unsigned long long)rounds); atomicAdd(&a.totals[3], (unsigned long long)dbg_radix);
             atomicAdd(&a.totals[4], (unsigned long long)dbg_slots_r); atomicAdd(&a.totals[5], (unsigned long long)dbg_slots_c);
             atomicAdd(&a.totals[6], 1ull); atomicAdd(&a.totals[7], (unsigned long long)dbg_act);
+            atomicAdd(&a.totals[8], (unsigned long long)t_fetch); atomicAdd(&a.totals[9], (unsigned long long)t_count);
+            atomicAdd(&a.totals[10], (unsigned long long)t_radix); atomicAdd(&a.totals[11], (unsigned long long)t_regroup);
+            atomicAdd(&a.totals[12], (unsigned long long)(clock64() - t_mark));
         }
     }
 }

@@ -1429,8 +1429,8 @@ struct Builder {
             hipLaunchKernelGGL((loc_plan_kernel<FIN_TILE, FIN_CAP>), dim3(div_up(ntiles, 256)), dim3(256), 0, stream, gid.as<u32>(), gstart.as<u32>(), M,
                                ntiles, loc_tiles.as<LocTile>());
         }
-        unsigned long long* ft = reinterpret_cast<unsigned long long*>(small.as<u8>() + 3640);
-        SA_HIP_CHECK(hipMemsetAsync(ft, 0, 64, stream));
+        unsigned long long* ft = reinterpret_cast<unsigned long long*>(small.as<u8>() + 3840);
+        SA_HIP_CHECK(hipMemsetAsync(ft, 0, 128, stream));
         SA_HIP_CHECK(hipMemsetAsync(done.p, 0, (size_t)M, stream));   // records of groups too large for a tile stay untouched
         FinArgs a;
         a.text = text.as<u8>(); a.n = n; a.b = b;
@@ -1440,8 +1440,8 @@ struct Builder {
         a.sa = sa; a.gflags = flags.as<u8>(); a.done = done.as<u8>();
         a.res_idx = ridx0.as<u32>(); a.res_fin = fin_flag.as<u8>(); a.totals = ft;
         hipLaunchKernelGGL(group_finish_kernel, dim3(ntiles), dim3(FIN_BLOCK), 0, stream, a, map);
-        unsigned long long ft_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        SA_HIP_CHECK(hipMemcpyAsync(ft_host, ft, 64, hipMemcpyDeviceToHost, stream));
+        unsigned long long ft_host[16] = {0};
+        SA_HIP_CHECK(hipMemcpyAsync(ft_host, ft, 128, hipMemcpyDeviceToHost, stream));
         const u32 tiles = div_up(M, BLD_TILE);
         hipLaunchKernelGGL(tiny_flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, gid.as<u32>(), done.as<u8>(), M, lf.as<u8>(),
                            counts.as<uint2>());
@@ -1454,6 +1454,9 @@ struct Builder {
             fprintf(stderr, "[sa_hip] finisher h=%llu M=%u G=%u tiles=%u (%llu non-empty): looked at %llu, resolved %llu -> M'=%u G'=%u; rounds %llu (%llu radix), "
                     "slots radix %llu counting %llu, active record-rounds %llu\n", (unsigned long long)h, M, G, ntiles, ft_host[6], ft_host[0], ft_host[1],
                     tot[0], tot[1], ft_host[2], ft_host[3], ft_host[4], ft_host[5], ft_host[7]);
+        if (debug_rounds && ft_host[6])
+            fprintf(stderr, "[sa_hip]   finisher cycles per tile (thread 0, clock64): fetch+keys %llu, counting sort %llu, radix sort %llu, regroup %llu, write-out %llu\n",
+                    ft_host[8] / ft_host[6], ft_host[9] / ft_host[6], ft_host[10] / ft_host[6], ft_host[11] / ft_host[6], ft_host[12] / ft_host[6]);
         if (tot[0] < M) {
             if (tot[0]) {
                 SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
