@@ -39,11 +39,11 @@ struct PinnedRing {
     bool ready = false;
     int init() {
         if (ready) return 0;
-        for (int i = 0; i < SLABS; ++i) {
-            SA_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&slab[i]), SLAB_BYTES, hipHostMallocDefault));
-            SA_HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        for (int i = 0; i < SLABS; ++i) {   // (a call that failed half way is completed by the next one: nothing is allocated twice)
+            if (!slab[i]) SA_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&slab[i]), SLAB_BYTES, hipHostMallocDefault));
+            if (!ev[i]) SA_HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
         }
-        SA_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        if (!copy_stream) SA_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         ready = true;
         return 0;
     }
