@@ -940,6 +940,7 @@ struct Builder {
     DevBuf apos0, apos1, apos2, aidx, gid, rkeys0, rkeys1, ridx0, ridx1, lf, tile_last, carry;
     RadixWorkspace radix;
     NarrowWorkspace narrow;
+    bool partial_char = true;         // SA_HIP_PARTIAL_CHAR: the 10-byte plan fills its 56 key bits with the top bits of one more character
     bool narrow48 = true;             // SA_HIP_NARROW48: 10-byte records for initial keys of 41..56 bits (radix_narrow48.hpp)
     u32* sa = nullptr;        // points into vals0/vals1 after a build (or into sa_own after load)
     DevBuf sa_own;
@@ -1055,6 +1056,7 @@ struct Builder {
         if (const char* e = diag_env("SA_HIP_FUSE_DIR")) fuse_directory = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_NARROW")) narrow_sort = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_NARROW48")) narrow48 = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_PARTIAL_CHAR")) partial_char = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_TEXT_PASS")) text_top_pass = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_WIDE_TEXT_PASS")) wide_text_pass = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_NARROW_K")) narrow_k = atoi(e) != 0;
@@ -1286,6 +1288,7 @@ struct Builder {
             // (also worth it beyond the cache's 256 MiB: at 26 bits the first batch after a build takes 0.125 ms with
             //  this read, 0.147 ms without, and the build time is the same within the noise)
             const u64 n16 = ((1ull << q_dbits) + 1) / 4;
+            if (const char* e = diag_env("SA_HIP_DIR_TOUCH")) { if (atoi(e) == 0) return 0; }
             hipLaunchKernelGGL(dir_touch_kernel, dim3(stream_grid(n16, 256)), dim3(256), 0, stream, qdir.as<uint4>(), n16,
                                reinterpret_cast<u32*>(small.as<u8>() + 3588));
             return 0;
@@ -1609,10 +1612,18 @@ struct Builder {
                                         n32, begin_bit, &kres, &vres, text_pass ? &src : nullptr, keep_narrow, sa64_out))) return rc;
             if (sa64_out) stats.widen_fused = 1;
         } else if (narrow48_path) {
+            // The 56 key bits hold k0 whole characters and, when the next one does not fit, its TOP bits: the key is the first
+            // 56 bits of the (k0 + 1)-character key.  Groups are still classes of the first k0 characters (h = k0) cut a little
+            // finer -- in an order consistent with the suffix order -- so fewer suffixes reach the finisher, for free.
             TextSource src;
             src.text = text.as<u8>(); src.b = b; src.k0 = k0;
+            int begin48 = begin_bit;
+            if (partial_char && b * k0 < 56 && b * (k0 + 1) > 56 && (L == 0 || (u32)(k0 + 1) <= L) && text_pass_applies(b, k0 + 1)) {
+                src.k0 = k0 + 1;
+                begin48 = 8;
+            }
             if ((rc = radix_sort_narrow48(radix, narrow, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(),
-                                          n32, begin_bit, &kres, &vres, src, sa64_out))) return rc;
+                                          n32, begin48, &kres, &vres, src, sa64_out))) return rc;
             if (sa64_out) stats.widen_fused = 1;
         } else {
             WideTextCtx wctx{text.as<u8>(), narrow.map_dev, n, b, k0};
