@@ -552,6 +552,7 @@ def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
 
     # gate: the gathered table equals what rank 0's own (built) index answers for the whole batch
     gate = None
+    one_gpu = None
     got = batch.results()
     if rank == 0:
         fb, fo = synth.query_batch(text, Qg, m, seed=0)
@@ -560,6 +561,31 @@ def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
         hits = (((got["second"].astype(np.int64) - got["first"].astype(np.int64) + 1) & 0xFFFFFFFF) > 0) & (got["first"] != 0xFFFFFFFF)
         gate = {"gathered_equals_single_gpu": same, "verify_violations": idx.verify(), "query_hit_rate": float(hits.mean())}
         gate["ok"] = bool(same and gate["verify_violations"] == 0)
+        # the SAME global batch on ONE GPU (rank 0's built index, whole batch in one launch per step): the 1-GPU value of this
+        # line's metric, so that strong scaling can be read off one line (the N = 1 bench line reports config 3, a build)
+        pat_all = torch.from_numpy(np.concatenate([np.ascontiguousarray(fb, dtype=np.uint8), np.zeros(64, np.uint8)])).to(dev)
+        off_all = torch.from_numpy(np.ascontiguousarray(fo, dtype=np.uint64).view(np.int64)).to(dev)
+        out_all = torch.empty(2 * Qg, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+
+        def whole():
+            if args.offsets_api:
+                idx.query_batch_device(pat_all.data_ptr(), off_all.data_ptr(), Qg, out_all.data_ptr())
+            else:
+                idx.query_batch_device_fixed(pat_all.data_ptr(), m, Qg, out_all.data_ptr())
+        for _ in range(max(1, args.warmup)):
+            whole()
+        idx.sync()
+        idx.query_stats()
+        w0 = time.perf_counter()
+        for _ in range(args.steps):
+            whole()
+        idx.sync()
+        wdt = time.perf_counter() - w0
+        one_gpu = {"queries_per_s": Qg * args.steps / wdt, "ms_per_step": wdt * 1e3 / args.steps,
+                   "search_kernel_ms": idx.query_stats()["kernel_ms_sum"] / args.steps,
+                   "note": "the whole batch on rank 0's GPU alone, ranges left in HBM (no gather): the 1-GPU reference for `value`"}
+        del pat_all, off_all, out_all
         if args.dump:   # tests/test_gpu_dist.py: the gathered ranges and the suffix array, to be checked against the oracle
             np.savez(args.dump, first=got["first"], second=got["second"], sa=idx.sa_u32() if N <= 100_000_000 else np.zeros(0, np.uint32))
     steps = args.steps
@@ -587,6 +613,7 @@ def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
             "search_only_queries_per_s": Qg * steps / (kern_ms_max / 1e3) if kern_ms_max > 0 else None,
             "build_ms": build_ms,
             "build_chars_per_s": N / (build_ms / 1e3),
+            "one_gpu_same_batch": one_gpu,
             "replicate_ms": bcast_ms,
             "replicate_bytes": bcast_bytes,
             "replicate_gbps": bcast_bytes / (bcast_ms / 1e3) / 1e9,

@@ -44,6 +44,7 @@ def test_config4_path_world1_child_process(gpu, oracle, tmp_path, mode, chunks, 
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["gate"]["ok"] and line["gate"]["verify_violations"] == 0, line["gate"]
     assert line["replicate_bytes"] >= 9 * n          # text + SA + narrow keys + directory all travelled
+    assert line["one_gpu_same_batch"]["queries_per_s"] > 0   # the 1-GPU reference for `value` rides in the same line
     # ... and against the oracle, not against the builder's own answers
     d = np.load(dump)
     text = synth.d1_uniform27(n)
