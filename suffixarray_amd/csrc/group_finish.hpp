@@ -301,10 +301,11 @@ __global__ __launch_bounds__(FIN_BLOCK, FIN_BLOCK == 512 ? 4 : 2) void group_fin
                     if (j < R) s_key[wh[rd[j] >> 16] + (rd[j] & 0xFFFFu)] = key[j];
                 __syncthreads();
                 if (pass + 1 < passes) {
+                    // (no barrier after these reads: the next write to s_key is the next pass's placement, three barriers on;
+                    //  the counters it zeroes first were last read before the barrier above)
 #pragma unroll
                     for (int j = 0; j < ITEMS; ++j)
                         if (j < R) key[j] = s_key[woff + j * WAVE];
-                    __syncthreads();
                 }
             }
         }
