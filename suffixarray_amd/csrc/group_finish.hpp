@@ -158,8 +158,11 @@ __global__ __launch_bounds__(FIN_BLOCK, FIN_BLOCK == 512 ? 4 : 2) void group_fin
     // SA_HIP_DEBUG_ROUNDS=1: cycles of thread 0 per phase (fetch + keys / counting sort / radix sort / regroup), totals[8..11]
     long long t_fetch = 0, t_count = 0, t_radix = 0, t_regroup = 0, t_mark = a.debug ? clock64() : 0;
     u32* wh = s_whist + wave * RADIX;
+    const u32 inv_b = 65536u / (u32)a.b + 1u;   // x / b == (x * inv_b) >> 16 for x <= 64, b <= 9
     while (true) {
-        const u32 A = s_A, G = s_G;
+        // the round's control values as SCALARS: read from LDS they sit in vector registers, and everything derived from them
+        // (rows per lane, characters per round, passes) turned every `if (j < R)` / `if (c < kc)` below into exec-mask branches
+        const u32 A = (u32)__builtin_amdgcn_readfirstlane((int)s_A), G = (u32)__builtin_amdgcn_readfirstlane((int)s_G);
         if (A == 0) break;
         if (rounds == a.max_rounds || stall >= 2) {
             // what is still tied goes back to the global path: its ORIGINAL group is left as it was
@@ -184,11 +187,11 @@ __global__ __launch_bounds__(FIN_BLOCK, FIN_BLOCK == 512 ? 4 : 2) void group_fin
             if (lane == 0 && mx) atomicMax(&s_maxg, mx);
         }
         sync_lds();   // s_maxg complete (LDS atomics above)
-        const bool counting = s_maxg <= a.count_max;
+        const bool counting = (u32)__builtin_amdgcn_readfirstlane((int)s_maxg) <= a.count_max;
         if (counting) dbg_slots_c += (u32)(WAVE * WAVES * R); else { dbg_slots_r += (u32)(WAVE * WAVES * R); ++dbg_radix; }
         dbg_act += A;
         const int gbits = fin_bits_for(G);
-        int kc = (64 - FIN_POS_BITS - gbits) / a.b;
+        int kc = (int)(((u32)(64 - FIN_POS_BITS - gbits) * inv_b) >> 16);
         if (kc > 8) kc = 8;
         if (!counting && a.radix_chars > 0 && kc > a.radix_chars) kc = a.radix_chars;   // cheap rounds until the large groups are apart
         if (a.L && (u32)kc > a.L - h) kc = (int)(a.L - h);   // h < L while anything is active
@@ -217,12 +220,25 @@ __global__ __launch_bounds__(FIN_BLOCK, FIN_BLOCK == 512 ? 4 : 2) void group_fin
                     const u64 avail = a.n - start;
                     const u64 w = wtext[j];
                     u64 chars = 0;
+                    if (a.b <= 8) {   // uniform
+                        // all eight codes looked up at once (eight independent LDS reads), packed as two 32-bit halves, the
+                        // first kc kept by one shift; codes past the end of the text are cleared by a mask (rare)
+                        const u32 w0 = (u32)w, w1 = (u32)(w >> 32);
+                        const u32 c0 = s_map[w0 & 255u], c1 = s_map[(w0 >> 8) & 255u], c2 = s_map[(w0 >> 16) & 255u], c3 = s_map[w0 >> 24];
+                        const u32 c4 = s_map[w1 & 255u], c5 = s_map[(w1 >> 8) & 255u], c6 = s_map[(w1 >> 16) & 255u], c7 = s_map[w1 >> 24];
+                        const u32 hi4 = (((((c0 << a.b) | c1) << a.b) | c2) << a.b) | c3;
+                        const u32 lo4 = (((((c4 << a.b) | c5) << a.b) | c6) << a.b) | c7;
+                        u64 all = ((u64)hi4 << (4 * a.b)) | lo4;          // character 0 on top, 8 * b <= 64 bits
+                        if (avail < 8) all = avail ? (all & (~0ull << (a.b * (8 - (int)avail)))) : 0ull;
+                        chars = all >> (a.b * (8 - kc));                   // 1 <= kc <= 8
+                    } else {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        if (c < kc) {
-                            const u32 byte = (u32)(w >> (8 * c)) & 255u;
-                            const u32 code = ((u64)c < avail) ? (u32)s_map[byte] : 0u;
-                            chars = (chars << a.b) | code;
+                        for (int c = 0; c < 8; ++c) {
+                            if (c < kc) {
+                                const u32 byte = (u32)(w >> (8 * c)) & 255u;
+                                const u32 code = ((u64)c < avail) ? (u32)s_map[byte] : 0u;
+                                chars = (chars << a.b) | code;
+                            }
                         }
                     }
                     key[j] = ((((u64)s_lgid[q] << cbits) | chars) << FIN_POS_BITS) | q;
@@ -351,7 +367,7 @@ __global__ __launch_bounds__(FIN_BLOCK, FIN_BLOCK == 512 ? 4 : 2) void group_fin
             const u32 ta = __shfl_up(ia, o), th = __shfl_up(ih, o);
             if (lane >= o) { ia += ta; ih += th; }
         }
-        const u32 tot_a = __shfl(ia, 63), tot_h = __shfl(ih, 63);
+        const u32 tot_a = (u32)__builtin_amdgcn_readlane((int)ia, 63), tot_h = (u32)__builtin_amdgcn_readlane((int)ih, 63);
         const u32 ea = ia - ca, eh = ih - ch;
         const u64 lt_mask = lanemask_lt();
 #pragma unroll
