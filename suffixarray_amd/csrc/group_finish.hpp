@@ -143,12 +143,37 @@ __global__ __launch_bounds__(FIN_BLOCK, FIN_BLOCK == 512 ? 4 : 2) void group_fin
     if (tid < 256) s_map[tid] = map.code[tid];
     for (u32 i = tid; i < CAP / 32; i += FIN_BLOCK) s_fail[i] = 0;
     const u32 G0 = a.gid[begin + cnt - 1] - gid0 + 1;
-    for (u32 p = tid; p < cnt; p += FIN_BLOCK) {
-        const u32 g = a.gid[begin + p] - gid0;
-        s_idx[p] = a.aidx[begin + p];
-        s_lgid[p] = (u16)g;
-        if (p == 0 || a.gid[begin + p - 1] - gid0 != g) { s_gq[g] = (u16)p; s_gpos[g] = (u16)p; }
-        a.res_fin[begin + p] = 0;
+    {   // the tile: every load of a thread is requested before the first is used (clamped indices; cnt <= CAP = ITEMS * FIN_BLOCK);
+        // group starts are found from the LDS copy afterwards (a third load per record made the kernel spill)
+        u32 gv[ITEMS], iv[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            u32 p = (u32)tid + (u32)it * FIN_BLOCK;
+            asm("" : "+v"(p));   // keeps these addresses from being shared with (and kept alive until) the write-out at the end
+            const u32 pc = p < cnt ? p : cnt - 1;
+            gv[it] = a.gid[begin + pc];
+            iv[it] = a.aidx[begin + pc];
+        }
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            u32 p = (u32)tid + (u32)it * FIN_BLOCK;
+            asm("" : "+v"(p));
+            if (p < cnt) {
+                s_idx[p] = iv[it];
+                s_lgid[p] = (u16)(gv[it] - gid0);
+                a.res_fin[begin + p] = 0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            u32 p = (u32)tid + (u32)it * FIN_BLOCK;
+            asm("" : "+v"(p));
+            if (p < cnt) {
+                const u32 g = s_lgid[p];
+                if (p == 0 || (u32)s_lgid[p - 1] != g) { s_gq[g] = (u16)p; s_gpos[g] = (u16)p; }
+            }
+        }
     }
     if (tid == 0) { s_A = cnt; s_G = G0; s_gq[G0] = (u16)cnt; }
     __syncthreads();
@@ -263,8 +288,16 @@ __global__ __launch_bounds__(FIN_BLOCK, FIN_BLOCK == 512 ? 4 : 2) void group_fin
                     if (q < A) {
                         const u32 g = s_lgid[q];
                         const u32 q0 = s_gq[g], q1 = s_gq[g + 1];
+                        // four members per step, their loads in flight together (one member per step waits a whole LDS round trip per
+                        // member; the wave runs as long as its largest group); reads past the group are masked out
                         u32 rank = 0;
-                        for (u32 m = q0; m < q1; ++m) rank += (s_key[m] < key[j]) ? 1u : 0u;
+                        const u64 kj = key[j];
+                        for (u32 m = q0; m < q1; m += 4) {
+                            const u64 k0 = s_key[m], k1 = s_key[(m + 1) & (CAP - 1u)], k2 = s_key[(m + 2) & (CAP - 1u)],
+                                      k3 = s_key[(m + 3) & (CAP - 1u)];
+                            rank += (k0 < kj ? 1u : 0u) + ((m + 1 < q1 && k1 < kj) ? 1u : 0u) + ((m + 2 < q1 && k2 < kj) ? 1u : 0u) +
+                                    ((m + 3 < q1 && k3 < kj) ? 1u : 0u);
+                        }
                         dst[j] = q0 + rank;
                     }
                 }
