@@ -331,7 +331,7 @@ def run_single(args, torch, _capi, synth, dev, device):
     bq = 2 * int(np.ceil(np.log2(max(N, 2)))) * (4 + m)              # reference bytes per query
     q_model = Q * steps * bq / (query_ms / 1e3) if query_ms > 0 else 0.0
     pmc_sort = committed_pmc("pmc_onesweep.json", N, PASS_KERNELS[dom])
-    qk = "query_kernel<true>" if last.get("narrow_k") else "query_kernel<false>"
+    qk = "query_kernel<true, 2>" if last.get("narrow_k") else "query_kernel<false, 2>"   # 2 = 32-byte key windows (the product path)
     pmc_q = committed_pmc("pmc_query.json", N, qk)
     rq = {"bound": "hbm", "kernel": qk, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
           "reference_model": {"bytes_per_query": bq, "achieved": q_model / 1e9,

@@ -114,8 +114,16 @@ int launch_query(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q
     if (Q) {
         u64 g = (Q + 255) / 256;
         if (g > 256u * 16u) g = 256u * 16u;
-        if (a.keys32) hipLaunchKernelGGL(query_kernel<true>, dim3((u32)g), dim3(256), 0, idx->stream, a, idx->b.qmap);
-        else hipLaunchKernelGGL(query_kernel<false>, dim3((u32)g), dim3(256), 0, idx->stream, a, idx->b.qmap);
+        const dim3 grid((u32)g), block(256);
+        if (a.keys32) {
+            if (a.sector_search == 2) hipLaunchKernelGGL((query_kernel<true, 2>), grid, block, 0, idx->stream, a, idx->b.qmap);
+            else if (a.sector_search == 1) hipLaunchKernelGGL((query_kernel<true, 1>), grid, block, 0, idx->stream, a, idx->b.qmap);
+            else hipLaunchKernelGGL((query_kernel<true, 0>), grid, block, 0, idx->stream, a, idx->b.qmap);
+        } else {
+            if (a.sector_search == 2) hipLaunchKernelGGL((query_kernel<false, 2>), grid, block, 0, idx->stream, a, idx->b.qmap);
+            else if (a.sector_search == 1) hipLaunchKernelGGL((query_kernel<false, 1>), grid, block, 0, idx->stream, a, idx->b.qmap);
+            else hipLaunchKernelGGL((query_kernel<false, 0>), grid, block, 0, idx->stream, a, idx->b.qmap);
+        }
     }
     SA_HIP_CHECK(hipEventRecord(ev[1], idx->stream));
     SA_HIP_CHECK(hipGetLastError());

@@ -36,15 +36,24 @@ __device__ __forceinline__ u64 load_be64(const u8* p) {
     return __builtin_bswap64(v);
 }
 
-// big-endian word j of the pattern, zero padded past c: one 8-byte load for a whole word, byte loads only
-// for the last partial word (nothing past the pattern's end is touched)
-__device__ __forceinline__ u64 pattern_word(const u8* q, u32 c, u32 j) {
-    const u32 o = j * 8;
-    if (o >= c) return 0ull;
-    if (c - o >= 8) return load_be64(q + o);
-    u64 v = 0;
-    for (u32 k = 0; k < 8; ++k) v = (v << 8) | (u64)((o + k < c) ? q[o + k] : 0);
-    return v;
+// the first 32 bytes of the pattern as four big-endian words, zero padded past c.  Every word that holds pattern bytes is
+// loaded whole -- the loads stand together, none waits for another -- and the last partial one is masked (the pattern buffer
+// is readable for 8 bytes past its end: sa_hip.h).  Round 3: the byte loop this replaces made every word's load wait for
+// the one before it.
+__device__ __forceinline__ void pattern_words(const u8* q, u32 c, u64 (&qw)[4]) {
+    // no branch around a load (the compiler ends every predicated block with a full wait): words past the pattern re-read its
+    // last word and are discarded by a select
+    const u32 last = c ? ((c - 1u) & ~7u) : 0u;
+    u64 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = load_be64(q + ((u32)(8 * j) < last ? (u32)(8 * j) : last));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 o = 8u * j;
+        u64 w = (o < c) ? v[j] : 0ull;
+        if (c > o && c - o < 8) w &= ~0ull << (64 - 8 * (c - o));
+        qw[j] = w;
+    }
 }
 
 // three-way compare of suffix `pos` against the pattern (c bytes): <0, 0, >0
@@ -53,13 +62,18 @@ __device__ __forceinline__ int cmp_suffix(const u8* __restrict__ text, u64 n, u3
                                           const u8* __restrict__ q, u32 c) {
     const u64 avail = (pos < n) ? n - pos : 0;   // (an adopted SA is range-checked on load; this keeps a stale entry harmless)
     const u32 l = avail < c ? (u32)avail : c;  // bytes of the suffix that exist
-    const u8* s = text + pos;
+    const u8* s = text + (pos < n ? pos : 0);
     u32 i = 0;
-    // whole 8-byte words (text is zero padded, reads past n are in bounds)
+    // whole 8-byte words (text is zero padded, reads past n are in bounds); every word of the register window that holds suffix
+    // bytes is requested before the first is compared: the words share a line or two, the waits do not add up
+    u64 aw[WORDS];
+    const u32 lastw = l ? ((l - 1u) & ~7u) : 0u;   // (no branch around a load: words past the compared length re-read the last one)
+#pragma unroll
+    for (int w = 0; w < WORDS; ++w) aw[w] = load_be64(s + ((u32)(8 * w) < lastw ? (u32)(8 * w) : lastw));
 #pragma unroll
     for (int w = 0; w < WORDS; ++w) {
         if (i + 8 <= l) {
-            const u64 a = load_be64(s + i);
+            const u64 a = aw[w];
             if (a != qw[w]) return a < qw[w] ? -1 : 1;
             i += 8;
         }
@@ -72,8 +86,12 @@ __device__ __forceinline__ int cmp_suffix(const u8* __restrict__ text, u64 n, u3
     if (i < l) {
         const u32 r = l - i;
         const u64 m = ~0ull << (64 - 8 * r);
-        const u64 a = load_be64(s + i) & m;
-        const u64 b = (i < (u32)WORDS * 8) ? (qw[i / 8] & m) : (load_be64(q + i) & m);
+        u64 a, b;
+        if (i < (u32)WORDS * 8) {   // inside the register window: i is a multiple of 8 here
+            a = 0; b = 0;
+#pragma unroll
+            for (int w = 0; w < WORDS; ++w) if (i == (u32)(8 * w)) { a = aw[w] & m; b = qw[w] & m; }
+        } else { a = load_be64(s + i) & m; b = load_be64(q + i) & m; }
         if (a != b) return a < b ? -1 : 1;
     }
     return l < c ? -1 : 0;
@@ -165,8 +183,10 @@ __device__ __forceinline__ u64 sector_bound(const KT* __restrict__ K, u64 l, u64
     return lo;
 }
 
-template <bool NARROW>
-__global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
+// MODE = QueryArgs::sector_search as a compile-time constant: the product path (2) does not carry the registers of the
+// 64-byte windows or of the plain bisection (diagnostic modes 1 and 0, kept for the tests)
+template <bool NARROW, int MODE = 2>
+__global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {   // MODE 2: 72 registers, 7 waves per SIMD (forced to 8: 0.0765 instead of 0.0734 ms)
     using KT = typename std::conditional<NARROW, u32, u64>::type;
     const KT* __restrict__ K = NARROW ? reinterpret_cast<const KT*>(a.keys32) : reinterpret_cast<const KT*>(a.keys);
     __shared__ u16 s_map[256];
@@ -174,14 +194,16 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
     __syncthreads();
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 qi = (u64)blockIdx.x * blockDim.x + threadIdx.x; qi < a.q; qi += stride) {
-        const u64 o = a.offsets ? a.offsets[qi] : qi * a.fixed_len;   // (uniform branch)
-        const u64 len = a.offsets ? a.offsets[qi + 1] - o : a.fixed_len;
+        u64 o = qi * a.fixed_len, len = a.fixed_len;
+        if (a.offsets) {   // (uniform branch; both loads requested together)
+            const u64 o0 = a.offsets[qi], o1 = a.offsets[qi + 1];
+            o = o0; len = o1 - o0;
+        }
         u32 c = len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)len;
         if (a.max_suffix_length && c > a.max_suffix_length) c = a.max_suffix_length;
         const u8* q = a.patterns + o;
         u64 qw[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) qw[j] = pattern_word(q, c, j);
+        pattern_words(q, c, qw);
 
         // ---- phase 1: narrow to the slots whose first P characters equal the pattern's -----------
         u64 lo = 0, hi = a.n;      // lb and ub both lie in [lo, hi]
@@ -191,10 +213,26 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
             u64 key_lo = 0;
             int sh = 64;
             const int pmax = (c < (u32)a.k0) ? (int)c : a.k0;
-            for (; P < pmax; ++P) {
-                const u32 byte = (P < 32) ? (u32)(qw[P >> 3] >> (56 - 8 * (P & 7))) & 255u : (u32)q[P];   // pattern bytes are in qw already
-                const u32 code = s_map[byte];
-                if (code == 0) break;   // byte absent from the text: nothing matches past here
+            // the pattern's characters as codes, four look-ups in flight at a time (one at a time waited an LDS round trip
+            // per character); a byte absent from the text (code 0) ends the key: nothing matches past it
+            bool stop = false;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (4 * g < pmax && !stop) {
+                    const u32 w32 = (g & 1) ? (u32)qw[g >> 1] : (u32)(qw[g >> 1] >> 32);
+                    const u32 cd[4] = {s_map[w32 >> 24], s_map[(w32 >> 16) & 255u], s_map[(w32 >> 8) & 255u], s_map[w32 & 255u]};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (P < pmax && !stop) {
+                            if (cd[t] == 0) stop = true;
+                            else { sh -= a.b; key_lo |= (u64)cd[t] << sh; ++P; }
+                        }
+                    }
+                }
+            }
+            for (; P < pmax && !stop; ++P) {   // keys of more than 32 characters (one-bit alphabets)
+                const u32 code = s_map[q[P]];
+                if (code == 0) break;
                 sh -= a.b;
                 key_lo |= (u64)code << sh;
             }
@@ -218,7 +256,7 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
                     t_hi2 = (KT)(key_hi >> a.lo_shift);
                     t_hi1 = ((key_lo >> 56) == (key_hi >> 56)) ? t_hi2 : (KT)~(KT)0;
                 } else { t_lo = (KT)key_lo; t_hi1 = t_hi2 = (KT)key_hi; }
-                if (a.sector_search && bh == bl && l < h) {
+                if (MODE != 0 && bh == bl && l < h) {
                     // one bucket: its keys lie in [bkt << ds, (bkt + 1) << ds); estimate the place of key_lo by its
                     // position in that interval (stored form: bits below the bucket bits, above lo_shift)
                     const int vs = NARROW ? a.lo_shift : 0;                         // low bit of the stored form
@@ -230,7 +268,7 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {
                         est = l + (((frac >> down) * (h - l)) >> (sb - down));
                         if (est >= h) est = h - 1;
                     }
-                    if (a.sector_search == 2) {   // (uniform) 32-byte windows
+                    if (MODE == 2) {   // 32-byte windows
                         SectorWindow<KT, 32> w;
                         lo = sector_bound<false>(K, l, h, t_lo, est, w, false);
                         hi = (lo < h) ? sector_bound<true>(K, lo, h, t_hi2, lo, w, true) : lo;
