@@ -24,8 +24,13 @@
 
 namespace sa {
 
-// records per thread: tiles of 8192, k32 and k16 staged side by side in LDS (48 KB), two workgroups per CU.
-constexpr int SEG48_ITEMS = 16;
+// records per thread: 14 -- tiles of 7168, k32 and k16 staged side by side in LDS (42 KB of 52 KB), 79 registers: THREE workgroups
+// per CU (210 KB of records in flight).  16 (two workgroups, 160 KB in flight) and 20 (two, 200 KB): the sort of the config-5
+// column at 4e8 characters 14.16 / 13.80 ms against 13.62 (tools/gpu_lib_ab.py, -DSA_SEG48_ITEMS).
+#ifndef SA_SEG48_ITEMS
+#define SA_SEG48_ITEMS 14
+#endif
+constexpr int SEG48_ITEMS = SA_SEG48_ITEMS;
 constexpr int SEG48_LAST_ITEMS = SEG48_ITEMS;
 
 struct Seg48Args {
@@ -184,7 +189,7 @@ __device__ __forceinline__ void seg48_tile(const Seg48Args& a, const u32 flat, c
 }
 
 template <int BLOCK, int ITEMS, bool ON16, bool LAST>
-__global__ __launch_bounds__(BLOCK, 4) void seg48_onesweep_kernel(Seg48Args a) {
+__global__ __launch_bounds__(BLOCK, ITEMS <= 14 ? 6 : 4) void seg48_onesweep_kernel(Seg48Args a) {
     constexpr int WAVES = BLOCK / WAVE;
     constexpr u32 TILE = BLOCK * ITEMS;
     __shared__ __attribute__((aligned(16))) u32 s_keys[TILE];   // reused for the other key array and the values
@@ -192,10 +197,13 @@ __global__ __launch_bounds__(BLOCK, 4) void seg48_onesweep_kernel(Seg48Args a) {
     __shared__ u32 s_whist[WAVES * RADIX];
     __shared__ u32 s_gdelta[RADIX];
     __shared__ u32 s_wsum[RADIX / WAVE];
-    __shared__ u32 s_t[RADIX + 1];
-    __shared__ u32 s_b[RADIX + 1];
-    __shared__ u32 s_c[NCHUNK + 1];
     __shared__ u32 s_flat;
+    // the plan (bucket starts, tile prefixes, chunk starts) is only read before the tile's first barrier: it lives in s_ext,
+    // which is first written after that barrier -- 2 KB that decide between two and three workgroups per CU at 14 records per thread
+    u32* s_t = reinterpret_cast<u32*>(s_ext);
+    u32* s_b = s_t + (RADIX + 1);
+    u32* s_c = s_b + (RADIX + 1);
+    static_assert((2 * (RADIX + 1) + NCHUNK + 1) * 4 <= TILE * 2, "plan fits the extension array");
 
     const int tid = threadIdx.x;
     u32 home = 0, t_home = 0;
