@@ -281,6 +281,14 @@ int sa_hip_csv_index_adopt(sa_hip_csv_index** out, const char* csv_file, const u
                            const char* column_names, uint32_t num_columns, uint32_t column_index, uint32_t max_suffix_length,
                            int device);
 void sa_hip_csv_index_destroy(sa_hip_csv_index* c);
+/* A column of more than `partition_bytes` (0 or > 2^32 - 2: 2^32 - 2) bytes as several independent indexes of WHOLE rows over
+ * the same file: the reference's partitions (engine.c:1437-1481 cuts the FILE every 2 GiB; suffix_array.pyx:221-247 answers
+ * from the partitions one after the other).  *out_parts: malloc'ed array of *num_parts handles (>= 1; each is destroyed with
+ * sa_hip_csv_index_destroy, the array with sa_hip_csv_index_free_parts); every sa_hip_csv_index entry point works on a part.
+ * The file is parsed once. */
+int sa_hip_csv_index_create_partitioned(sa_hip_csv_index*** out_parts, uint32_t* num_parts, const char* csv_file, const char* search_column,
+                                        uint32_t max_suffix_length, int device, uint64_t partition_bytes);
+void sa_hip_csv_index_free_parts(sa_hip_csv_index** parts);
 /* The device index underneath (batched queries, statistics, verification); owned by the CSV index. */
 sa_hip_index* sa_hip_csv_index_handle(sa_hip_csv_index* c);
 uint64_t sa_hip_csv_index_num_rows(const sa_hip_csv_index* c);

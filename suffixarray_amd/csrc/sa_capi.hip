@@ -1053,6 +1053,71 @@ int sa_hip_csv_index_create(sa_hip_csv_index** out, const char* csv_file, const 
     return 0;
 }
 
+// The reference cuts a CSV file into 2 GiB partitions, one suffix array each (engine.c:1437-1481), and answers a query from
+// the partitions one after the other (suffix_array.pyx:221-247).  Here one index holds up to 2^32 - 2 COLUMN bytes whatever
+// the file's size; a column beyond `partition_bytes` is cut at ROW boundaries (no match is lost at a cut) into several
+// independent sa_hip_csv_index objects over the same mapped file -- every entry point works on a part as on a whole index.
+int sa_hip_csv_index_create_partitioned(sa_hip_csv_index*** out_parts, uint32_t* num_parts, const char* csv_file, const char* search_column,
+                                        uint32_t max_suffix_length, int device, uint64_t partition_bytes) {
+    if (!out_parts || !num_parts || !csv_file || !search_column) return fail(SA_HIP_EINVAL, "sa_hip_csv_index_create_partitioned: NULL argument");
+    *out_parts = nullptr; *num_parts = 0;
+    if (max_suffix_length == 0) return fail(SA_HIP_EINVAL, "sa_hip_csv_index_create_partitioned: max_suffix_length must be >= 1");
+    if (partition_bytes == 0 || partition_bytes > 0xFFFFFFFEull) partition_bytes = 0xFFFFFFFEull;
+    sa_hip_csv_column col;
+    std::thread warm;
+    try { warm = std::thread([device]() { if (hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr); }); } catch (...) {}
+    int rc = sa_hip_csv_extract_column(csv_file, search_column, &col);
+    if (warm.joinable()) warm.join();
+    if (rc) return rc;
+    // rows [cut[p], cut[p + 1]) form part p: as many whole rows as fit partition_bytes (a row's text includes its separator)
+    std::vector<u64> cut;
+    std::vector<sa_hip_csv_index*> parts;
+    try {
+        cut.push_back(0);
+        u64 begin_text = 0;
+        for (u64 r = 0; r < col.num_rows; ++r) {
+            const u64 row_end = (r + 1 < col.num_rows) ? col.row_text_starts[r + 1] : col.text_len;
+            if (row_end - col.row_text_starts[r] > partition_bytes) {
+                sa_hip_csv_free(&col);
+                return fail(SA_HIP_EINVAL, "sa_hip_csv_index_create_partitioned: one row's column text exceeds partition_bytes");
+            }
+            if (row_end - begin_text > partition_bytes) { cut.push_back(r); begin_text = col.row_text_starts[r]; }
+        }
+        cut.push_back(col.num_rows);
+        if (cut.size() == 2 && col.num_rows == 0) cut.assign({0, 0});
+        for (size_t p = 0; p + 1 < cut.size() && !rc; ++p) {
+            const u64 r0 = cut[p], r1 = cut[p + 1];
+            const u64 t0 = (r0 < col.num_rows) ? col.row_text_starts[r0] : col.text_len;
+            const u64 t1 = (r1 < col.num_rows) ? col.row_text_starts[r1] : col.text_len;
+            sa_hip_csv_index* c = new sa_hip_csv_index();
+            parts.push_back(c);
+            c->path = csv_file;
+            c->column_index = col.column_index;
+            const char* q = col.column_names;
+            for (u32 i = 0; i < col.num_columns; ++i) { c->columns.emplace_back(q); q += c->columns.back().size() + 1; }
+            c->row_file_offsets.assign(col.row_file_offsets + r0, col.row_file_offsets + r1 + 1);
+            std::vector<u64> starts(r1 - r0);
+            for (u64 r = r0; r < r1; ++r) starts[r - r0] = col.row_text_starts[r] - t0;
+            const u64 len = t1 - t0;
+            rc = sa_hip_index_create(&c->idx, len ? len : 1, device);
+            if (!rc) rc = sa_hip_index_build(c->idx, col.text + t0, len, max_suffix_length);
+            if (!rc) rc = sa_hip_index_set_rows(c->idx, starts.data(), r1 - r0);
+            if (!rc) rc = csv_index_finish(c);
+        }
+    } catch (const std::bad_alloc&) {
+        rc = fail(SA_HIP_ENOMEM, "sa_hip_csv_index_create_partitioned: out of host memory");
+    }
+    sa_hip_csv_free(&col);
+    sa_hip_csv_index** arr = rc ? nullptr : static_cast<sa_hip_csv_index**>(malloc((parts.size() ? parts.size() : 1) * sizeof(sa_hip_csv_index*)));
+    if (!rc && !arr) rc = fail(SA_HIP_ENOMEM, "sa_hip_csv_index_create_partitioned: out of host memory");
+    if (rc) { for (sa_hip_csv_index* c : parts) sa_hip_csv_index_destroy(c); return rc; }
+    for (size_t p = 0; p < parts.size(); ++p) arr[p] = parts[p];
+    *out_parts = arr;
+    *num_parts = (uint32_t)parts.size();
+    return 0;
+}
+void sa_hip_csv_index_free_parts(sa_hip_csv_index** parts) { free(parts); }
+
 int sa_hip_csv_index_adopt(sa_hip_csv_index** out, const char* csv_file, const uint8_t* text, const uint32_t* SA, uint64_t n,
                            const uint64_t* row_text_starts, const uint64_t* row_file_offsets, uint64_t num_rows,
                            const char* column_names, uint32_t num_columns, uint32_t column_index, uint32_t max_suffix_length, int device) {

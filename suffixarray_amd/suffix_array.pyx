@@ -56,6 +56,10 @@ cdef extern from "sa_hip.h":
                                const char* column_names, uint32_t num_columns, uint32_t column_index,
                                uint32_t max_suffix_length, int device) nogil
     void sa_hip_csv_index_destroy(sa_hip_csv_index* c) nogil
+    int sa_hip_csv_index_create_partitioned(sa_hip_csv_index*** out_parts, uint32_t* num_parts, const char* csv_file,
+                                            const char* search_column, uint32_t max_suffix_length, int device,
+                                            uint64_t partition_bytes) nogil
+    void sa_hip_csv_index_free_parts(sa_hip_csv_index** parts) nogil
     sa_hip_index* sa_hip_csv_index_handle(sa_hip_csv_index* c) nogil
     uint64_t sa_hip_csv_index_num_rows(const sa_hip_csv_index* c) nogil
     uint32_t sa_hip_csv_index_num_columns(const sa_hip_csv_index* c) nogil
@@ -262,11 +266,41 @@ cdef class SuffixArray:
         cdef int rc
         cdef uint32_t L = self._L
         cdef int device = self.device
+        cdef sa_hip_csv_index** parts = NULL
+        cdef uint32_t nparts = 0, i
+        cdef uint64_t pb = self._partition_bytes
+        cdef SuffixArray part
         self._release()
         with nogil:
-            rc = sa_hip_csv_index_create(&self._csv, fnp, colp, L, device)
+            rc = sa_hip_csv_index_create_partitioned(&parts, &nparts, fnp, colp, L, device, pb)
         _check(rc)
-        self._adopt_csv(filename)
+        try:
+            if nparts == 1:
+                self._csv = parts[0]
+                parts[0] = NULL
+                self._adopt_csv(filename)
+                return
+            # a column beyond partition_bytes: one index per run of whole rows (engine.c:1437-1481 cuts the file every 2 GiB),
+            # answered one after the other (pyx:221-247); each part is a CSV-mode SuffixArray of its own
+            self._parts = []
+            for i in range(nparts):
+                part = SuffixArray.__new__(SuffixArray)
+                part._L = L
+                part.device = device
+                part._parts = None
+                part._partition_bytes = pb
+                part._csv = parts[i]
+                parts[i] = NULL
+                part._adopt_csv(filename)
+                self._parts.append(part)
+            self.csv_filename = filename
+            self.columns = list(self._parts[0].columns)
+            self._mode = "partitioned"
+        finally:
+            for i in range(nparts):
+                if parts[i] != NULL:
+                    sa_hip_csv_index_destroy(parts[i])
+            sa_hip_csv_index_free_parts(parts)
 
     cdef _adopt_csv(self, str filename):
         cdef uint32_t i
@@ -410,7 +444,7 @@ cdef class SuffixArray:
     #    pyx:310-423).  Versioned directory: meta.json + raw little-endian arrays; load() adopts them, no rebuild. -------
     @property
     def partitions(self):
-        """The per-partition indexes of a partitioned documents index (else [self])."""
+        """The per-partition indexes of a partitioned (documents or CSV) index (else [self])."""
         return list(self._parts) if self._parts is not None else [self]
 
     def save(self, directory: str):
@@ -471,7 +505,11 @@ cdef class SuffixArray:
         cdef SuffixArray self = cls(max_suffix_length=meta["max_suffix_length"], device=device)
         if meta.get("mode") == "partitioned":
             self._parts = [cls.load(_os.path.join(directory, "part%04d" % i), device) for i in range(int(meta["parts"]))]
-            self._documents = [d for p in self._parts for d in (<SuffixArray>p)._documents]
+            if self._parts and (<SuffixArray>self._parts[0])._mode == "csv":
+                self.columns = list((<SuffixArray>self._parts[0]).columns)
+                self.csv_filename = (<SuffixArray>self._parts[0]).csv_filename
+            else:
+                self._documents = [d for p in self._parts for d in (<SuffixArray>p)._documents]
             self._mode = "partitioned"
             return self
         text = np.fromfile(_os.path.join(directory, "text.u8"), dtype=np.uint8)

@@ -75,3 +75,44 @@ def check_partitioned(SuffixArray, tmp_path):
     assert sorted(back.query_records("quick", k=10**6)) == sorted(d for d in docs if "quick" in d.lower())
     for x in (one, part, back):
         x.close()
+
+
+def check_partitioned_csv(SuffixArray, tmp_path):
+    """a CSV column cut into partitions of whole rows (sa_hip_csv_index_create_partitioned; the reference cuts the file every
+    2 GiB, engine.c:1437-1481, and answers from the partitions one after the other, pyx:221-247): the same rows as one index over
+    the whole column, quoted fields and commas inside them included, k honoured across partitions, save / load."""
+    import csv as _csv
+    rng = np.random.default_rng(23)
+    words = ["Acme", "Globex", "Initech", "Umbrella", "Hooli", "Vehement", "Massive Dynamic", "Stark", "Wayne", "Wonka"]
+    tails = ["", " Inc", " LLC", ", Inc.", " Ltd", ' "The Best"']
+    rows = [(str(i), words[int(rng.integers(0, len(words)))] + " " + words[int(rng.integers(0, len(words)))] + tails[int(rng.integers(0, len(tails)))],
+             ["US", "DE", "FR"][i % 3]) for i in range(600)]
+    path = str(tmp_path / "companies.csv")
+    with open(path, "w", newline="") as f:
+        w = _csv.writer(f)
+        w.writerow(["id", "company_name", "country"])
+        w.writerows(rows)
+    one = SuffixArray(csv_file=path, search_column="company_name", max_suffix_length=32)
+    part = SuffixArray(csv_file=path, search_column="company_name", max_suffix_length=32, partition_bytes=1500)
+    assert len(one.partitions) == 1 and len(part.partitions) >= 6
+    assert part.columns == ["id", "company_name", "country"]
+
+    def ids(recs):
+        return sorted(int(r["id"]) for r in recs)
+    for q in ("acme", "INC", ", inc.", "massive dynamic", "the best", "zzz", "a", "hooli w"):
+        exp = sorted(int(r[0]) for r in rows if q.lower() in r[1].lower())
+        assert ids(one.query_records(q, k=10**6)) == exp, q
+        got = part.query_records(q, k=10**6)
+        assert ids(got) == exp, q
+        assert all(set(r) == {"id", "company_name", "country"} for r in got)
+        few = part.query_records(q, k=4)
+        assert len(few) == min(4, len(exp)) and all(int(r["id"]) in exp for r in few)
+    got = part.query_records_batch(["acme", "", "wonka", "zzz"], k=7)
+    assert got[1] == [] and got[3] == [] and len(got[0]) == min(7, sum("acme" in r[1].lower() for r in rows))
+    assert all("wonka" in r["company_name"].lower() for r in got[2])
+    part.save(str(tmp_path / "csvparts"))
+    back = SuffixArray.load(str(tmp_path / "csvparts"))
+    assert len(back.partitions) == len(part.partitions) and back.columns == part.columns
+    assert ids(back.query_records("stark", k=10**6)) == sorted(int(r[0]) for r in rows if "stark" in r[1].lower())
+    for x in (one, part, back):
+        x.close()

@@ -106,6 +106,11 @@ def test_python_api_documents(gpu):
     s.close()
 
 
+def test_python_api_partitioned_csv(gpu, tmp_path):
+    from suffixarray_amd import SuffixArray
+    cases.check_partitioned_csv(SuffixArray, tmp_path)
+
+
 def test_python_api_partitioned_documents(gpu, tmp_path):
     from suffixarray_amd import SuffixArray
     cases.check_partitioned(SuffixArray, tmp_path)
