@@ -229,7 +229,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--offsets-api", action="store_true", help="query through sa_hip_query_batch_device (offsets array) instead of the fixed-length entry")
     ap.add_argument("--separate-widen", action="store_true", help="int64 output by a widening pass after the build (A/B against the fused form)")
-    ap.add_argument("--dist-chunks", type=int, default=4, help="pieces a rank's slice is searched and gathered in (pipelined)")
+    ap.add_argument("--dist-chunks", type=int, default=4, help="pieces a rank's slice is searched and gathered in (pipelined); at most this many, none under 1e6 patterns")
+    ap.add_argument("--dist-min-chunk", type=int, default=1_000_000, help="patterns a pipelined piece carries at least")
     ap.add_argument("--dist-mode", choices=("all_gather", "gather_to_root"), default="all_gather")
     ap.add_argument("--dump", default=None, help="config 4: write the gathered ranges (+ the SA for N <= 1e8) to this .npz (tests)")
     ap.add_argument("--exercise-dist", action="store_true",
@@ -525,7 +526,10 @@ def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
     # ONE global batch, the same on every rank; this rank's slice goes to its GPU
     lo, hi = shard_bounds(Qg, world, rank)
     q_buf, q_off = synth.query_batch(text, Qg, m, seed=0, lo=lo, hi=hi)
-    batch = ShardedBatch(q_buf, q_off, Qg, world, rank, dev, chunks=args.dist_chunks, mode=args.dist_mode,
+    # a chunk should carry enough patterns to pay for its collective (tens of microseconds of launch + rendezvous each): at most
+    # --dist-chunks pieces, none under a million patterns -- 4 pieces at N <= 2, 2 at N = 4, 1 at N = 8 for the default batch
+    chunks = max(1, min(args.dist_chunks, (hi - lo) // max(1, args.dist_min_chunk)))
+    batch = ShardedBatch(q_buf, q_off, Qg, world, rank, dev, chunks=chunks, mode=args.dist_mode,
                          search_stream=torch.cuda.ExternalStream(searcher.stream, device=dev))
 
     def search(pat_t, off_t, start, count, out_t):

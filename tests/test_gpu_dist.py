@@ -33,7 +33,7 @@ def test_config4_path_world1_child_process(gpu, oracle, tmp_path, mode, chunks, 
     n, q, m = 20_000_000, 400_003, 16
     dump = str(tmp_path / "ranges.npz")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--exercise-dist", "--chars", str(n), "--queries-global", str(q),
-           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--dist-mode", mode, "--dist-chunks", str(chunks), "--dump", dump]
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--dist-mode", mode, "--dist-chunks", str(chunks), "--dist-min-chunk", "1", "--dump", dump]
     if offsets_api:
         cmd.append("--offsets-api")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
