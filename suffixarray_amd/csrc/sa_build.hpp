@@ -450,9 +450,10 @@ __global__ __launch_bounds__(BLD_BLOCK) void compact_kernel(const u8* __restrict
     }
 }
 
-// Dense variant (a large share of the domain is active): elements are visited in lane-strided
-// order so that the reads of src_pos / src_idx and the compacted stores coalesce; costs one
-// workgroup scan per 256 elements, which the sparse variant above avoids.
+// Dense variant (a large share of the domain is active): elements are visited in lane-strided order so that the reads of
+// src_pos / src_idx and the compacted stores coalesce.  A wave owns 1024 consecutive elements of the tile (16 rows of 64): its
+// flag bytes are requested together, counted by ballots, and ONE workgroup exchange gives the wave its base -- the first form
+// exchanged counts after every row of 256 (32 barriers per tile, every row's flag load waiting behind one).
 __global__ __launch_bounds__(BLD_BLOCK) void compact_dense_kernel(const u8* __restrict__ lf, u32 n,
                                                                   const uint2* __restrict__ offsets,
                                                                   const u32* __restrict__ src_pos,
@@ -462,32 +463,39 @@ __global__ __launch_bounds__(BLD_BLOCK) void compact_dense_kernel(const u8* __re
     __shared__ u32 s_a[WAVES], s_h[WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u64 lt = lanemask_lt();
+    const u64 wbase = (u64)blockIdx.x * BLD_TILE + (u64)wave * (WAVE * BLD_ITEMS);
+    u32 f[BLD_ITEMS];
+#pragma unroll
+    for (int it = 0; it < BLD_ITEMS; ++it) {
+        const u64 j = wbase + (u64)it * WAVE + lane;
+        const u32 v = lf[j < n ? j : (u64)n - 1];   // (no branch around the load; n >= 1)
+        f[it] = j < n ? v : 0u;
+    }
+    u32 ca = 0, ch = 0;
+#pragma unroll
+    for (int it = 0; it < BLD_ITEMS; ++it) {
+        ca += (u32)__popcll(__ballot((f[it] & 2u) != 0));
+        ch += (u32)__popcll(__ballot((f[it] & 3u) == 3u));
+    }
+    if (lane == 0) { s_a[wave] = ca; s_h[wave] = ch; }
+    __syncthreads();
     const uint2 off = offsets[blockIdx.x];
     u32 a_off = off.x, h_off = off.y;
-    const u64 base = (u64)blockIdx.x * BLD_TILE;
-    for (int it = 0; it < BLD_ITEMS; ++it) {
-        const u64 j = base + (u64)it * BLD_BLOCK + threadIdx.x;
-        const u32 f = (j < n) ? lf[j] : 0u;
-        const bool act = (f & 2u) != 0;
-        const bool ah = act && (f & 1u);
-        const u64 ba = __ballot(act), bh = __ballot(ah);
-        if (lane == 0) { s_a[wave] = (u32)__popcll(ba); s_h[wave] = (u32)__popcll(bh); }
-        __syncthreads();
-        u32 wa = 0, wh = 0, ta = 0, th = 0;
+    for (int w = 0; w < wave; ++w) { a_off += s_a[w]; h_off += s_h[w]; }
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            if (w < wave) { wa += s_a[w]; wh += s_h[w]; }
-            ta += s_a[w]; th += s_h[w];
-        }
+    for (int it = 0; it < BLD_ITEMS; ++it) {
+        const u64 j = wbase + (u64)it * WAVE + lane;
+        const bool act = (f[it] & 2u) != 0;
+        const bool ah = (f[it] & 3u) == 3u;
+        const u64 ba = __ballot(act), bh = __ballot(ah);
         if (act) {
-            const u32 m = a_off + wa + (u32)__popcll(ba & lt);
-            const u32 g = h_off + wh + (u32)__popcll(bh & lt) + (ah ? 1u : 0u) - 1u;
+            const u32 m = a_off + (u32)__popcll(ba & lt);
+            const u32 g = h_off + (u32)__popcll(bh & lt) + (ah ? 1u : 0u) - 1u;
             dst_pos[m] = src_pos ? src_pos[j] : (u32)j;
             dst_idx[m] = src_idx[j];
             dst_gid[m] = g;
         }
-        a_off += ta; h_off += th;
-        __syncthreads();
+        a_off += (u32)__popcll(ba); h_off += (u32)__popcll(bh);
     }
 }
 
