@@ -1192,7 +1192,13 @@ struct Builder {
     void launch_compact(const u8* lf_in, u32 cnt, u32 active, const u32* src_pos, const u32* src_idx, u32* dst_pos,
                         u32* dst_idx, u32* dst_gid) {
         const u32 tiles = div_up(cnt, BLD_TILE);
-        if ((u64)active * 8 >= cnt)
+#ifndef SA_DENSE_DIV
+#define SA_DENSE_DIV 100
+#endif
+        // >= 1 % active: the lane-strided variant.  The sparse one costs ~0.5 ps per slot + ~16 ps per active element (D1 at n = 1e9,
+        // 0.35 % active: 0.565 ms against 0.670 ms for the dense one; 10 % active after a finisher run: 2.1 ps per slot against ~0.8),
+        // the crossover lies near 1 % (12.5 % until the dense variant lost its per-row barriers)
+        if ((u64)active * SA_DENSE_DIV >= cnt)
             hipLaunchKernelGGL(compact_dense_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, lf_in, cnt, counts.as<uint2>(), src_pos,
                                src_idx, dst_pos, dst_idx, dst_gid);
         else
