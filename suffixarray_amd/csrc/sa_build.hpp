@@ -237,7 +237,9 @@ __global__ __launch_bounds__(BLD_BLOCK) void flags_kernel(const u64* __restrict_
         for (int i = threadIdx.x; i <= 256; i += BLD_BLOCK) s_b[i] = nk.bstart[i];
         __syncthreads();
     }
-    const u64 base = (u64)blockIdx.x * BLD_TILE;
+    const u32 ntiles = (u32)(((u64)n + BLD_TILE - 1) / BLD_TILE);
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // SA_FLAGS_PERSIST: a resident grid walks the tiles
+    const u64 base = (u64)tile * BLD_TILE;
     u32 ca = 0, ch = 0;
     u32 bkt = 0;   // NARROW: bucket of the slot looked at last; a thread's slots only move forward
     if (NARROW) {
@@ -335,7 +337,9 @@ __global__ __launch_bounds__(BLD_BLOCK) void flags_kernel(const u64* __restrict_
     if (threadIdx.x == 0) {
         u32 ta = 0, th = 0;
         for (int w = 0; w < BLD_BLOCK / WAVE; ++w) { ta += s_a[w]; th += s_h[w]; }
-        counts[blockIdx.x] = make_uint2(ta, th);
+        counts[tile] = make_uint2(ta, th);
+    }
+    __syncthreads();   // s_a / s_h are reused by the next tile
     }
 }
 
@@ -1224,11 +1228,18 @@ struct Builder {
             d.dstat = radix.dstat;
             SA_HIP_CHECK(hipMemsetAsync(d.gap_count, 0, 4, stream));
         }
+        // a resident-sized grid that walks the tiles instead of one short-lived workgroup per 4096 slots (244 141 of them at n = 1e9):
+        // flags_kernel<true> 2.0 -> 1.55 ms at n = 1e9 with 32768 workgroups (4096 / 8192 / 16384 / 65536: 1.78 / 1.8 / 1.88 / 1.72;
+        // 2048, the exact resident count: 2.24), -6 % at 5e8, -18 % at 7.77e8, -9 % at 2e9 (profiles/r03_flags_grid.log)
+#ifndef SA_FLAGS_GRID
+#define SA_FLAGS_GRID 32768
+#endif
+        const u32 fgrid = (SA_FLAGS_GRID && tiles > (u32)SA_FLAGS_GRID) ? (u32)SA_FLAGS_GRID : tiles;
         if (nk)
-            hipLaunchKernelGGL(flags_kernel<true>, dim3(tiles), dim3(BLD_BLOCK), 0, stream, (const u64*)nullptr, *nk, cnt, lf_out,
+            hipLaunchKernelGGL(flags_kernel<true>, dim3(fgrid), dim3(BLD_BLOCK), 0, stream, (const u64*)nullptr, *nk, cnt, lf_out,
                                counts.as<uint2>(), apos, sidx, sa, flags.as<u8>(), d);
         else
-            hipLaunchKernelGGL(flags_kernel<false>, dim3(tiles), dim3(BLD_BLOCK), 0, stream, keys, NarrowKeys{}, cnt, lf_out,
+            hipLaunchKernelGGL(flags_kernel<false>, dim3(fgrid), dim3(BLD_BLOCK), 0, stream, keys, NarrowKeys{}, cnt, lf_out,
                                counts.as<uint2>(), apos, sidx, sa, flags.as<u8>(), d);
         if (with_directory) {
             hipLaunchKernelGGL(dir_fill_kernel, dim3(1024), dim3(256), 0, stream, d);

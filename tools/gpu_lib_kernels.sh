@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for lib in "$@"; do
   export SA_HIP_LIB=$GRAFT_REPO_ROOT/$lib
   tag=$(basename $lib .so)
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_lk_$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/lk_$tag.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_lk_$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary $BENCH_ARGS > gpurun_out/lk_$tag.log 2>&1 || exit 1
   python3 - "$tag" <<'P'
 import csv, glob, sys
 f = glob.glob('gpurun_out/prof_lk_%s/*/*_kernel_stats.csv' % sys.argv[1])[0]
