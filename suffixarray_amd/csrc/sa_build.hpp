@@ -581,7 +581,8 @@ __device__ __forceinline__ int cmp_suffix_pair(const u8* __restrict__ text, u64 
 __global__ __launch_bounds__(256) void tiny_groups_kernel(const u8* __restrict__ text, u64 n, const u32* __restrict__ aidx,
                                                           const u32* __restrict__ gid, const u32* __restrict__ apos, u32 m_count,
                                                           u64 h, u32 limit, int truncated, u32* __restrict__ sa,
-                                                          u8* __restrict__ gflags, u8* __restrict__ done) {
+                                                          u8* __restrict__ gflags, u8* __restrict__ done,
+                                                          int64_t* __restrict__ sa64 = nullptr) {   // 64-bit build: the int64 copy too
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 m = (u64)blockIdx.x * blockDim.x + threadIdx.x; m < m_count; m += stride) {
         const u32 g = gid[m];
@@ -627,6 +628,7 @@ __global__ __launch_bounds__(256) void tiny_groups_kernel(const u8* __restrict__
             if (k < size) {
                 const u32 slot = apos[m + k];
                 sa[slot] = v[k];
+                if (sa64) sa64[slot] = (int64_t)v[k];   // (uniform)
                 gflags[slot] = 1;
                 done[m + k] = 1;
             }
@@ -1692,6 +1694,7 @@ struct Builder {
             launch_compact(flags.as<u8>(), n32, M, nullptr, sa, apos0.as<u32>(), aidx.as<u32>(), gid.as<u32>());
         }
         const u32 M0 = (M && (L == 0 || h < L)) ? M : 0;   // the first active list (apos0) stays: the slots an int64 copy has to be patched at
+        bool patched_by_tiny = false;
         lst_cur = apos0.as<u32>();
         lst_nxt = apos1.as<u32>();
         lst_first = true;
@@ -1711,12 +1714,14 @@ struct Builder {
             SA_HIP_CHECK(hipMemsetAsync(done.p, 0, (size_t)M, stream));
             const u32 limit = L ? (u32)(L - h) : TINY_DEPTH;
             hipLaunchKernelGGL(tiny_groups_kernel, dim3(stream_grid(M, 256)), dim3(256), 0, stream, text.as<u8>(), n, aidx.as<u32>(),
-                               gid.as<u32>(), apos_cur, M, h, limit, L ? 1 : 0, sa, flags.as<u8>(), done.as<u8>());
+                               gid.as<u32>(), apos_cur, M, h, limit, L ? 1 : 0, sa, flags.as<u8>(), done.as<u8>(),
+                               (sa64_out && stats.widen_fused) ? sa64_out : (int64_t*)nullptr);
             const u32 tiles = div_up(M, BLD_TILE);
             hipLaunchKernelGGL(tiny_flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, gid.as<u32>(), done.as<u8>(), M,
                                lf.as<u8>(), counts.as<uint2>());
             if ((rc = scan_counts(tiles, tot))) return rc;
             stats.tiny_resolved = (u64)M - tot[0];
+            if (tot[0] == 0 && M == M0) patched_by_tiny = true;   // every slot the int64 copy lacked has just been written in both widths
             if (tot[0] < M) {
                 if (tot[0]) {
                     SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
@@ -1832,7 +1837,7 @@ struct Builder {
         if (sa64_out) {
             if (!stats.widen_fused)
                 hipLaunchKernelGGL(widen_kernel, dim3(stream_grid(n / 4 + 1, 256)), dim3(256), 0, stream, (const u32*)sa, n, sa64_out);
-            else if (M0)
+            else if (M0 && !patched_by_tiny)
                 hipLaunchKernelGGL(widen_patch_kernel, dim3(stream_grid(M0, 256)), dim3(256), 0, stream, (const u32*)apos0.as<u32>(), M0,
                                    (const u32*)sa, sa64_out);
         }
