@@ -1054,9 +1054,14 @@ struct Builder {
         return k < 1 ? 1 : k;
     }
 
+    // Small device-to-host reads go through a pinned mailbox: a hipMemcpyAsync into PAGEABLE memory blocks the host until the copy
+    // has landed, so reading two values cost two round trips (the kernel trace of a build shows ~20 us of idle GPU per such copy).
+    u8* mbox = nullptr;
+    enum : size_t { MB_FREQ = 0, MB_PILOT = 2048, MB_TOTALS = 2064, MB_STATUS = 2112, MB_BIG = 2240, MB_FT = 2304, MB_BEST = 2560, MB_BYTES = 4096 };
     int init(u64 nmax, hipStream_t s) {
         stream = s;
         n_max = nmax;
+        if (!mbox) SA_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&mbox), MB_BYTES, hipHostMallocDefault));
         const u64 cap = nmax ? nmax : 1;
         int rc;
         if ((rc = text.ensure(cap + TEXT_PAD + 16))) return rc;
@@ -1120,6 +1125,8 @@ struct Builder {
         if (ev_begin) (void)hipEventDestroy(ev_begin);
         if (ev_end) (void)hipEventDestroy(ev_end);
         ev_begin = ev_end = nullptr;
+        if (mbox) (void)hipHostFree(mbox);
+        mbox = nullptr;
     }
 
     // text must already be in text.p[0..n); pads it and computes freq + code map
@@ -1129,7 +1136,8 @@ struct Builder {
         u64* dh = small.as<u64>();
         SA_HIP_CHECK(hipMemsetAsync(dh, 0, 256 * sizeof(u64), stream));
         if (n) hipLaunchKernelGGL(byte_hist_kernel, dim3(stream_grid(n, 256 * 64)), dim3(256), 0, stream, text.as<u8>(), n, dh);
-        SA_HIP_CHECK(hipMemcpyAsync(freq, dh, sizeof freq, hipMemcpyDeviceToHost, stream));
+        static_assert(sizeof freq == 2048, "mailbox layout");
+        SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_FREQ, dh, sizeof freq, hipMemcpyDeviceToHost, stream));
         // pilot (independent of the histogram: raw bytes), only for texts large enough to matter
         u32 pilot_dups = 0;
         pilot_dup_share = 0.0;
@@ -1141,9 +1149,11 @@ struct Builder {
             u32* pd = reinterpret_cast<u32*>(pilot.as<u8>() + (size_t)PILOT_SLOTS * 8);
             hipLaunchKernelGGL(pilot_kernel, dim3(PILOT_SAMPLES / 256), dim3(256), 0, stream, text.as<u8>(), n, 8,
                                pilot.as<unsigned long long>(), pd);
-            SA_HIP_CHECK(hipMemcpyAsync(&pilot_dups, pd, 4, hipMemcpyDeviceToHost, stream));
+            SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_PILOT, pd, 4, hipMemcpyDeviceToHost, stream));
         }
         SA_HIP_CHECK(hipStreamSynchronize(stream));
+        memcpy(freq, mbox + MB_FREQ, sizeof freq);
+        if (run_pilot) memcpy(&pilot_dups, mbox + MB_PILOT, 4);
         if (run_pilot) pilot_dup_share = (double)pilot_dups / (double)PILOT_SAMPLES;
         sigma = 0;
         memset(&map, 0, sizeof map);
@@ -1159,9 +1169,12 @@ struct Builder {
     DeviceStatus status_seen{};
     bool status_fresh = false;
     int read_totals(u32* totals_host) {
-        SA_HIP_CHECK(hipMemcpyAsync(totals_host, small.as<u8>() + 2048, 2 * sizeof(u32), hipMemcpyDeviceToHost, stream));
-        SA_HIP_CHECK(hipMemcpyAsync(&status_seen, radix.dstat, sizeof status_seen, hipMemcpyDeviceToHost, stream));
+        static_assert(sizeof(DeviceStatus) <= MB_BIG - MB_STATUS, "mailbox layout");
+        SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_TOTALS, small.as<u8>() + 2048, 2 * sizeof(u32), hipMemcpyDeviceToHost, stream));
+        SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_STATUS, radix.dstat, sizeof status_seen, hipMemcpyDeviceToHost, stream));
         SA_HIP_CHECK(hipStreamSynchronize(stream));
+        memcpy(totals_host, mbox + MB_TOTALS, 2 * sizeof(u32));
+        memcpy(&status_seen, mbox + MB_STATUS, sizeof status_seen);
         status_fresh = true;
         return 0;
     }
@@ -1173,8 +1186,9 @@ struct Builder {
             st = status_seen;
             status_fresh = false;
         } else {
-            SA_HIP_CHECK(hipMemcpyAsync(&st, radix.dstat, sizeof st, hipMemcpyDeviceToHost, stream));
+            SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_STATUS, radix.dstat, sizeof st, hipMemcpyDeviceToHost, stream));
             SA_HIP_CHECK(hipStreamSynchronize(stream));
+            memcpy(&st, mbox + MB_STATUS, sizeof st);
         }
         if (st.error != 0) {
             (void)hipMemsetAsync(radix.dstat, 0, sizeof(DeviceStatus), stream);
@@ -1407,8 +1421,9 @@ struct Builder {
         hipLaunchKernelGGL((loc_plan_kernel<LOC_TILE, LOC_CAP>), dim3(div_up(ntiles, 256)), dim3(256), 0, stream, gid.as<u32>(), gstart.as<u32>(), M, ntiles,
                            loc_tiles.as<LocTile>());
         hipLaunchKernelGGL(loc_scan_kernel, dim3(1), dim3(1024), 0, stream, loc_tiles.as<LocTile>(), ntiles, total_dev);
-        SA_HIP_CHECK(hipMemcpyAsync(&big, total_dev, 4, hipMemcpyDeviceToHost, stream));
+        SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_BIG, total_dev, 4, hipMemcpyDeviceToHost, stream));
         SA_HIP_CHECK(hipStreamSynchronize(stream));
+        memcpy(&big, mbox + MB_BIG, 4);
         if ((u64)big * 2 > M)
             return global_sort();
         }
@@ -1471,11 +1486,12 @@ struct Builder {
         a.res_idx = ridx0.as<u32>(); a.res_fin = fin_flag.as<u8>(); a.totals = ft;
         hipLaunchKernelGGL(group_finish_kernel, dim3(ntiles), dim3(FIN_BLOCK), 0, stream, a, map);
         unsigned long long ft_host[16] = {0};
-        SA_HIP_CHECK(hipMemcpyAsync(ft_host, ft, 128, hipMemcpyDeviceToHost, stream));
+        SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_FT, ft, 128, hipMemcpyDeviceToHost, stream));
         const u32 tiles = div_up(M, BLD_TILE);
         hipLaunchKernelGGL(tiny_flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, gid.as<u32>(), done.as<u8>(), M, lf.as<u8>(),
                            counts.as<uint2>());
-        if ((rc = scan_counts(tiles, tot))) return rc;   // synchronises: ft_host is valid
+        if ((rc = scan_counts(tiles, tot))) return rc;   // synchronises: the mailbox holds the finisher's totals
+        memcpy(ft_host, mbox + MB_FT, 128);
         stats.finisher_runs += 1;
         stats.finisher_records += ft_host[0];
         stats.finisher_resolved += (u64)M - tot[0];
@@ -1526,8 +1542,9 @@ struct Builder {
                                per_bad.as<u8>(), per_table.as<uint2>());
             hipLaunchKernelGGL(per_pick_kernel, dim3(1), dim3(1024), 0, stream, per_table.as<uint2>(), best_dev);
             u32 best[2] = {0, 0};
-            SA_HIP_CHECK(hipMemcpyAsync(best, best_dev, 8, hipMemcpyDeviceToHost, stream));
+            SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_BEST, best_dev, 8, hipMemcpyDeviceToHost, stream));
             SA_HIP_CHECK(hipStreamSynchronize(stream));
+            memcpy(best, mbox + MB_BEST, 8);
             if (debug_rounds) fprintf(stderr, "[sa_hip] period finisher M=%u G=%u: difference %u covers %u records\n", M, G, best[0], best[1]);
             if (best[0] == 0 || (u64)best[1] * 8 < M) break;   // nothing periodic enough (left)
             covered += best[1];
