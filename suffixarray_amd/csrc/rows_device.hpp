@@ -17,6 +17,7 @@
 namespace sa {
 
 constexpr u32 ROWS_K_MAX = 4096;
+constexpr int ROWS_COARSE_SHIFT = 8;
 constexpr u32 ROWS_SLOTS_SMALL = 4096;    // k <= 1536: 32 KB of LDS
 constexpr u32 ROWS_K_SMALL = 1536;
 constexpr u32 ROWS_SLOTS_LARGE = 16384;   // k <= 4096: 128 KB of LDS (one workgroup per CU)
@@ -27,20 +28,20 @@ struct RowsArgs {
     u64 q;
     const u64* row_starts;           // [num_rows], ascending, row_starts[0] = 0
     u64 num_rows;
+    const u64* coarse;               // [coarse_n] = row_starts[j << ROWS_COARSE_SHIFT]: every 256th start (1.5 MB for 50M rows: stays in
+    u64 coarse_n;                    //  the L2), or nullptr: a hit finds its row in 18 cached + 8 local probes instead of 26 HBM round trips
     u32 k;                           // 1 .. ROWS_K_MAX (and <= what SLOTS allows)
     u32* out_rows;                   // [q][k]
     u32* out_counts;                 // [q]
 };
 
+// the rows of ONE range (all 256 threads of the workgroup; s_tab: SLOTS entries, s_wcnt: 4)
 template <u32 SLOTS>
-__global__ __launch_bounds__(256) void rows_kernel(RowsArgs a) {
-    __shared__ unsigned long long s_tab[SLOTS];   // (row + 1) << 32 | index of the row's first hit; 0 = empty
-    __shared__ u32 s_wcnt[4];
+__device__ __forceinline__ void rows_of_range(const RowsArgs& a, const u64 qi, const sa_hip_pair_u32 rg, unsigned long long* s_tab, u32* s_wcnt) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int SHIFT = 32 - (SLOTS == 4096 ? 12 : 14);
     static_assert(SLOTS == 4096 || SLOTS == 16384, "table sizes");
-    for (u64 qi = blockIdx.x; qi < a.q; qi += gridDim.x) {
-        const sa_hip_pair_u32 rg = a.ranges[qi];
+    {
         u32 count = 0;
         if (rg.first != 0xFFFFFFFFu && (u32)(rg.second - rg.first + 1u) != 0u) count = rg.second - rg.first + 1u;   // miss: second = first - 1
         for (u32 i = tid; i < SLOTS; i += 256) s_tab[i] = 0ull;
@@ -53,6 +54,16 @@ __global__ __launch_bounds__(256) void rows_kernel(RowsArgs a) {
             if (valid) {
                 const u64 pos = a.sa[(u64)rg.first + i];
                 u64 lo = 0, hi = a.num_rows;             // first row whose start is > pos
+                if (a.coarse) {                          // (uniform) narrow [lo, hi) to one block of 256 rows through the small table
+                    u64 cl = 0, ch = a.coarse_n;         // first block whose first row starts > pos (>= 1: coarse[0] = 0 <= pos)
+                    while (cl < ch) {
+                        const u64 mid = (cl + ch) >> 1;
+                        if (a.coarse[mid] <= pos) cl = mid + 1; else ch = mid;
+                    }
+                    lo = (cl - 1) << ROWS_COARSE_SHIFT;  // row_starts[lo] <= pos
+                    const u64 end = cl << ROWS_COARSE_SHIFT;
+                    hi = end < a.num_rows ? end : a.num_rows;   // cl < coarse_n: row_starts[end] > pos
+                }
                 while (lo < hi) {
                     const u64 mid = (lo + hi) >> 1;
                     if (a.row_starts[mid] <= pos) lo = mid + 1; else hi = mid;
@@ -85,6 +96,33 @@ __global__ __launch_bounds__(256) void rows_kernel(RowsArgs a) {
         if (tid == 0) a.out_counts[qi] = have < a.k ? have : a.k;
         __syncthreads();       // the table is cleared for the next query
     }
+}
+
+template <u32 SLOTS>
+__global__ __launch_bounds__(256) void rows_kernel(RowsArgs a) {
+    __shared__ unsigned long long s_tab[SLOTS];   // (row + 1) << 32 | index of the row's first hit; 0 = empty
+    __shared__ u32 s_wcnt[4];
+    for (u64 qi = blockIdx.x; qi < a.q; qi += gridDim.x) rows_of_range<SLOTS>(a, qi, a.ranges[qi], s_tab, s_wcnt);
+}
+
+// ONE query, one launch (the latency path of get_matching_records_file): thread 0 searches, the workgroup then collects the rows
+// of the range it found -- the search kernel and the rows kernel of the batch path without the launch in between.
+// (sa_query.hpp is included before this header: query_one.)
+template <bool NARROW, u32 SLOTS>
+__global__ __launch_bounds__(256) void query_rows_one_kernel(QueryArgs qa, CodeMap map, RowsArgs ra) {
+    __shared__ unsigned long long s_tab[SLOTS];
+    __shared__ u32 s_wcnt[4];
+    __shared__ u16 s_map[256];
+    __shared__ sa_hip_pair_u32 s_rg;
+    s_map[threadIdx.x] = map.code[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const sa_hip_pair_u32 rg = query_one<NARROW, 2>(qa, s_map, 0);
+        qa.out[0] = rg;
+        s_rg = rg;
+    }
+    __syncthreads();
+    rows_of_range<SLOTS>(ra, 0, s_rg, s_tab, s_wcnt);
 }
 
 inline void launch_rows(hipStream_t stream, const RowsArgs& a) {

@@ -45,6 +45,8 @@ struct sa_hip_index {
     sa_hip_query_stats qstats{};
     std::vector<u64> row_starts;   // sa_hip_index_set_rows: offset of every row (document, CSV field) in the indexed text
     DevBuf rows_dev;               // the same table in HBM (rows_device.hpp)
+    DevBuf rows_coarse;            // every 256th entry of it (stays cached)
+    u64 rows_coarse_n = 0;
     DevBuf r_rows, r_counts;       // results of the rows kernel (batched form)
     std::unique_ptr<HostIndex> host;   // set: the opt-in no-GPU path of config 1 (host_index.hpp); nothing below touches HIP then
     bool receiving = false;        // sa_hip_index_replica_reserve .. _commit: the buffers are being filled by the caller
@@ -91,9 +93,7 @@ int resolve_query_events(sa_hip_index* idx, int count) {
     return 0;
 }
 
-int launch_query(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q, sa_hip_pair_u32* out_dev, u64 fixed_len = 0) {
-    if (idx->q_pending == sa_hip_index::QRING) { int rc = resolve_query_events(idx, 1); if (rc) return rc; }
-    hipEvent_t* ev = idx->q_ev[idx->q_head];
+QueryArgs query_args(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q, sa_hip_pair_u32* out_dev, u64 fixed_len) {
     QueryArgs a;
     a.fixed_len = fixed_len;
     a.text = idx->b.text.as<u8>();
@@ -110,6 +110,13 @@ int launch_query(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q
     a.sector_search = idx->b.sector_search;
     a.dir = idx->b.qdir.as<u32>();
     a.b = idx->b.q_b; a.k0 = idx->b.q_k0; a.dbits = idx->b.q_dbits;
+    return a;
+}
+
+int launch_query(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q, sa_hip_pair_u32* out_dev, u64 fixed_len = 0) {
+    if (idx->q_pending == sa_hip_index::QRING) { int rc = resolve_query_events(idx, 1); if (rc) return rc; }
+    hipEvent_t* ev = idx->q_ev[idx->q_head];
+    const QueryArgs a = query_args(idx, pat_dev, off_dev, Q, out_dev, fixed_len);
     SA_HIP_CHECK(hipEventRecord(ev[0], idx->stream));
     if (Q) {
         u64 g = (Q + 255) / 256;
@@ -214,7 +221,7 @@ void sa_hip_index_destroy(sa_hip_index* idx) {
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     idx->b.destroy();
     idx->q_pat.release(); idx->q_off.release(); idx->q_out.release(); idx->widen.release();
-    idx->rows_dev.release(); idx->r_rows.release(); idx->r_counts.release();
+    idx->rows_dev.release(); idx->rows_coarse.release(); idx->r_rows.release(); idx->r_counts.release();
     if (idx->qh_host) (void)hipHostFree(idx->qh_host);
     for (int i = 0; i < sa_hip_index::QRING; ++i)
         for (int k = 0; k < 2; ++k) if (idx->q_ev[i][k]) (void)hipEventDestroy(idx->q_ev[i][k]);
@@ -808,7 +815,15 @@ int sa_hip_index_set_rows(sa_hip_index* idx, const uint64_t* row_text_starts, ui
     if (rc) return rc;
     if ((rc = idx->rows_dev.ensure((size_t)(num_rows ? num_rows : 1) * 8))) return rc;
     if (num_rows) SA_HIP_CHECK(hipMemcpyAsync(idx->rows_dev.p, row_text_starts, (size_t)num_rows * 8, hipMemcpyHostToDevice, idx->stream));
-    SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+    // every 256th start as a table of its own: the rows kernel's search runs through it first
+    std::vector<u64> coarse;
+    try {
+        for (u64 r = 0; r < num_rows; r += (1ull << ROWS_COARSE_SHIFT)) coarse.push_back(row_text_starts[r]);
+    } catch (const std::bad_alloc&) { return fail(SA_HIP_ENOMEM, "sa_hip_index_set_rows: out of host memory"); }
+    idx->rows_coarse_n = coarse.size();
+    if ((rc = idx->rows_coarse.ensure((coarse.size() ? coarse.size() : 1) * 8))) return rc;
+    if (!coarse.empty()) SA_HIP_CHECK(hipMemcpyAsync(idx->rows_coarse.p, coarse.data(), coarse.size() * 8, hipMemcpyHostToDevice, idx->stream));
+    SA_HIP_CHECK(hipStreamSynchronize(idx->stream));   // (the staging vector lives until here)
     return 0;
 }
 
@@ -849,13 +864,21 @@ static int query_rows_device_locked(sa_hip_index* idx, const uint8_t* pattern, u
     memcpy(h + QH_OFF_OFFSETS, off, sizeof off);
     if (len) memcpy(h + QH_OFF_PATTERN, pattern, len);
     memset(h + QH_OFF_PATTERN + len, 0, 64);
-    if ((rc = launch_query(idx, d + QH_OFF_PATTERN, reinterpret_cast<const u64*>(d + QH_OFF_OFFSETS), 1,
-                           reinterpret_cast<sa_hip_pair_u32*>(d)))) return rc;
     RowsArgs a;
     a.sa = idx->b.sa; a.ranges = reinterpret_cast<const sa_hip_pair_u32*>(d); a.q = 1;
     a.row_starts = idx->rows_dev.as<u64>(); a.num_rows = idx->row_starts.size(); a.k = k;
+    a.coarse = (idx->rows_coarse_n > 1) ? idx->rows_coarse.as<u64>() : nullptr; a.coarse_n = idx->rows_coarse_n;
     a.out_rows = reinterpret_cast<u32*>(d + QH_OFF_HITS); a.out_counts = reinterpret_cast<u32*>(d + 8);
-    launch_rows(idx->stream, a);
+    if (idx->b.sector_search == 2 && k <= ROWS_K_SMALL) {
+        // the product configuration: search + rows in ONE launch (no events: this path is not part of the query statistics)
+        const QueryArgs qa = query_args(idx, d + QH_OFF_PATTERN, reinterpret_cast<const u64*>(d + QH_OFF_OFFSETS), 1, reinterpret_cast<sa_hip_pair_u32*>(d), 0);
+        if (qa.keys32) hipLaunchKernelGGL((query_rows_one_kernel<true, ROWS_SLOTS_SMALL>), dim3(1), dim3(256), 0, idx->stream, qa, idx->b.qmap, a);
+        else hipLaunchKernelGGL((query_rows_one_kernel<false, ROWS_SLOTS_SMALL>), dim3(1), dim3(256), 0, idx->stream, qa, idx->b.qmap, a);
+    } else {
+        if ((rc = launch_query(idx, d + QH_OFF_PATTERN, reinterpret_cast<const u64*>(d + QH_OFF_OFFSETS), 1,
+                               reinterpret_cast<sa_hip_pair_u32*>(d)))) return rc;
+        launch_rows(idx->stream, a);
+    }
     SA_HIP_CHECK(hipGetLastError());
     SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
     if (range) memcpy(range, h, sizeof *range);
@@ -948,6 +971,7 @@ int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, co
             RowsArgs a;
             a.sa = idx->b.sa; a.ranges = idx->q_out.as<sa_hip_pair_u32>(); a.q = Q;
             a.row_starts = idx->rows_dev.as<u64>(); a.num_rows = idx->row_starts.size(); a.k = k;
+            a.coarse = (idx->rows_coarse_n > 1) ? idx->rows_coarse.as<u64>() : nullptr; a.coarse_n = idx->rows_coarse_n;
             a.out_rows = idx->r_rows.as<u32>(); a.out_counts = idx->r_counts.as<u32>();
             launch_rows(idx->stream, a);
             SA_HIP_CHECK(hipGetLastError());

@@ -185,15 +185,12 @@ __device__ __forceinline__ u64 sector_bound(const KT* __restrict__ K, u64 l, u64
 
 // MODE = QueryArgs::sector_search as a compile-time constant: the product path (2) does not carry the registers of the
 // 64-byte windows or of the plain bisection (diagnostic modes 1 and 0, kept for the tests)
-template <bool NARROW, int MODE = 2>
-__global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {   // MODE 2: 72 registers, 7 waves per SIMD (forced to 8: 0.0765 instead of 0.0734 ms)
+// one query: the inclusive SA range of pattern qi (conventions of get_substring_positions, engine.c:896-898, 916-917)
+template <bool NARROW, int MODE>
+__device__ __forceinline__ sa_hip_pair_u32 query_one(const QueryArgs& a, const u16* s_map, const u64 qi) {
     using KT = typename std::conditional<NARROW, u32, u64>::type;
     const KT* __restrict__ K = NARROW ? reinterpret_cast<const KT*>(a.keys32) : reinterpret_cast<const KT*>(a.keys);
-    __shared__ u16 s_map[256];
-    s_map[threadIdx.x] = map.code[threadIdx.x];
-    __syncthreads();
-    const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 qi = (u64)blockIdx.x * blockDim.x + threadIdx.x; qi < a.q; qi += stride) {
+    {
         u64 o = qi * a.fixed_len, len = a.fixed_len;
         if (a.offsets) {   // (uniform branch; both loads requested together)
             const u64 o0 = a.offsets[qi], o1 = a.offsets[qi + 1];
@@ -330,8 +327,17 @@ __global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) { 
         sa_hip_pair_u32 res;
         if (lb == a.n) { res.first = 0xFFFFFFFFu; res.second = 0xFFFFFFFFu; }
         else { res.first = (u32)lb; res.second = (u32)(ub - 1); }
-        a.out[qi] = res;
+        return res;
     }
+}
+
+template <bool NARROW, int MODE = 2>
+__global__ __launch_bounds__(256) void query_kernel(QueryArgs a, CodeMap map) {   // MODE 2: 72 registers, 7 waves per SIMD (forced to 8: 0.0765 instead of 0.0734 ms)
+    __shared__ u16 s_map[256];
+    s_map[threadIdx.x] = map.code[threadIdx.x];
+    __syncthreads();
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 qi = (u64)blockIdx.x * blockDim.x + threadIdx.x; qi < a.q; qi += stride) a.out[qi] = query_one<NARROW, MODE>(a, s_map, qi);
 }
 
 }  // namespace sa
