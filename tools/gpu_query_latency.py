@@ -33,5 +33,6 @@ it = iter(pats)
 print("C query_rows k=1000 (ctypes) %s" % timed(lambda q: idx.query_rows(q.lower().encode(), 1000)))
 print("C query_rows k=1    (ctypes) %s" % timed(lambda q: idx.query_rows(q.lower().encode(), 1)))
 print("C query_batch of ONE (ctypes) %s" % timed(lambda q: idx.query_batch([q.lower().encode()])))
+print("C query_hits max 16 (ctypes)  %s" % timed(lambda q: idx.query_hits(q.lower().encode(), 16)))
 print("len(names) =", len(names), " mean results =", np.mean([len(sa.query_records(q)) for q in names[:300]]))
 os.remove(path)
