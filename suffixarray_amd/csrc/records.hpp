@@ -24,7 +24,7 @@ namespace sa {
 // distinct rows of the hits SA[first .. second], in order of first appearance, at most k.
 // fetch(pos, count, out) copies SA[pos .. pos + count) to the host; first_hits = the hits already fetched with the range.
 template <class Fetch>
-inline int distinct_rows(const std::vector<u64>& row_starts, sa_hip_pair_u32 range, u32 k, const u32* first_hits, u32 n_first,
+inline int distinct_rows(const HostU64Array& row_starts, sa_hip_pair_u32 range, u32 k, const u32* first_hits, u32 n_first,
                          Fetch&& fetch, std::vector<u64>& rows) {
     rows.clear();
     if (k == 0 || row_starts.empty() || range.first == 0xFFFFFFFFu || (u32)(range.second - range.first + 1u) == 0u) return 0;

@@ -43,7 +43,7 @@ struct sa_hip_index {
     hipEvent_t w_begin = nullptr, w_end = nullptr;   // sa_hip_index_widen_device
     double widen_ms = 0.0;                           // < 0: recorded, not yet resolved
     sa_hip_query_stats qstats{};
-    std::vector<u64> row_starts;   // sa_hip_index_set_rows: offset of every row (document, CSV field) in the indexed text
+    HostU64Array row_starts;   // sa_hip_index_set_rows: offset of every row (document, CSV field) in the indexed text
     DevBuf rows_dev;               // the same table in HBM (rows_device.hpp)
     DevBuf rows_coarse;            // every 256th entry of it (stays cached)
     u64 rows_coarse_n = 0;
@@ -64,7 +64,7 @@ struct sa_hip_comm {
 // tables + the memory-mapped file the rows are copied out of
 struct sa_hip_csv_index {
     sa_hip_index* idx = nullptr;
-    std::vector<u64> row_file_offsets;   // num_rows + 1
+    HostU64Array row_file_offsets;   // num_rows + 1
     std::vector<std::string> columns;
     u32 column_index = 0;
     std::string path;
@@ -852,6 +852,15 @@ int sa_hip_index_query_stats(const sa_hip_index* idx_c, sa_hip_query_stats* out)
 
 // ---- record retrieval (engine.c:920-999, 1168-1215, 1326-1390; pyx:87-101) -----------------------
 
+static int set_rows_locked_tail(sa_hip_index* idx);
+
+// the row table of the library's own CSV extractor: a malloc'ed array that is ascending by construction -- adopted, not copied
+static int set_rows_adopt(sa_hip_index* idx, uint64_t* malloced_starts, uint64_t num_rows) {
+    std::lock_guard<std::mutex> g(idx->mu);
+    idx->row_starts.adopt(malloced_starts, (size_t)num_rows);
+    return set_rows_locked_tail(idx);
+}
+
 int sa_hip_index_set_rows(sa_hip_index* idx, const uint64_t* row_text_starts, uint64_t num_rows) {
     if (!idx || (!row_text_starts && num_rows)) return fail(SA_HIP_EINVAL, "sa_hip_index_set_rows: NULL argument");
     if (num_rows && row_text_starts[0] != 0) return fail(SA_HIP_EINVAL, "sa_hip_index_set_rows: the first row must start at offset 0");
@@ -860,6 +869,12 @@ int sa_hip_index_set_rows(sa_hip_index* idx, const uint64_t* row_text_starts, ui
     std::lock_guard<std::mutex> g(idx->mu);
     try { idx->row_starts.assign(row_text_starts, row_text_starts + num_rows); }
     catch (const std::bad_alloc&) { return fail(SA_HIP_ENOMEM, "sa_hip_index_set_rows: out of host memory"); }
+    return set_rows_locked_tail(idx);
+}
+
+static int set_rows_locked_tail(sa_hip_index* idx) {   // (idx->mu held) the table in HBM for the rows kernel
+    const u64* row_text_starts = idx->row_starts.data();
+    const u64 num_rows = idx->row_starts.size();
     if (idx->host) return 0;
     // ... and in HBM for the rows kernel
     int rc = set_device(idx->device);
@@ -958,7 +973,7 @@ int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t 
         int rc = query_hits_locked(idx, pattern, len, cap, &rg, first.data(), &nh);
         if (rc) return rc;
         if (range) *range = rg;
-        const std::vector<u64>& starts = idx->row_starts;
+        const HostU64Array& starts = idx->row_starts;
         if (starts.empty()) return 0;
         std::vector<u64> rows;
         rc = distinct_rows(starts, rg, k, first.data(), nh,
@@ -1060,7 +1075,7 @@ int sa_hip_index_rows_for_range(sa_hip_index* idx, sa_hip_pair_u32 range, uint32
     if (k && idx->row_starts.empty()) return fail(SA_HIP_EINVAL, "sa_hip_index_rows_for_range: no row table (sa_hip_index_set_rows)");
     if ((u64)k > idx->row_starts.size()) k = (u32)idx->row_starts.size();
     try {
-        const std::vector<u64>& starts = idx->row_starts;
+        const HostU64Array& starts = idx->row_starts;
         if (starts.empty()) return 0;
         std::vector<u64> rows;
         int rc = distinct_rows(starts, range, k, nullptr, 0,
@@ -1141,16 +1156,26 @@ int sa_hip_csv_index_create_partitioned(sa_hip_csv_index*** out_parts, uint32_t*
     sa_hip_csv_column col;
     std::thread warm;
     try { warm = std::thread([device]() { if (hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr); }); } catch (...) {}
+    const bool timing = diag_env("SA_HIP_CSV_TIMING") && atoi(diag_env("SA_HIP_CSV_TIMING")) != 0;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sa_hip csv] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     int rc = sa_hip_csv_extract_column(csv_file, search_column, &col);
     if (warm.joinable()) warm.join();
     if (rc) return rc;
+    lap("extract (all of the above)");
     // rows [cut[p], cut[p + 1]) form part p: as many whole rows as fit partition_bytes (a row's text includes its separator)
     std::vector<u64> cut;
     std::vector<sa_hip_csv_index*> parts;
     try {
         cut.push_back(0);
         u64 begin_text = 0;
-        for (u64 r = 0; r < col.num_rows; ++r) {
+        // (the usual case -- the whole column fits one index -- needs no walk over the rows)
+        for (u64 r = 0; col.text_len > partition_bytes && r < col.num_rows; ++r) {
             const u64 row_end = (r + 1 < col.num_rows) ? col.row_text_starts[r + 1] : col.text_len;
             if (row_end - col.row_text_starts[r] > partition_bytes) {
                 sa_hip_csv_free(&col);
@@ -1170,19 +1195,37 @@ int sa_hip_csv_index_create_partitioned(sa_hip_csv_index*** out_parts, uint32_t*
             c->column_index = col.column_index;
             const char* q = col.column_names;
             for (u32 i = 0; i < col.num_columns; ++i) { c->columns.emplace_back(q); q += c->columns.back().size() + 1; }
-            c->row_file_offsets.assign(col.row_file_offsets + r0, col.row_file_offsets + r1 + 1);
-            std::vector<u64> starts(r1 - r0);
-            for (u64 r = r0; r < r1; ++r) starts[r - r0] = col.row_text_starts[r] - t0;
+            const bool whole = (r0 == 0 && r1 == col.num_rows);   // one part: the extractor's tables are adopted as they are
+            std::vector<u64> starts;
+            if (whole) {
+                c->row_file_offsets.adopt(col.row_file_offsets, (size_t)col.num_rows + 1);
+                col.row_file_offsets = nullptr;
+            } else {
+                c->row_file_offsets.assign(col.row_file_offsets + r0, col.row_file_offsets + r1 + 1);
+                starts.resize(r1 - r0);
+                for (u64 r = r0; r < r1; ++r) starts[r - r0] = col.row_text_starts[r] - t0;
+            }
             const u64 len = t1 - t0;
+            lap("cuts, row tables");
             rc = sa_hip_index_create(&c->idx, len ? len : 1, device);
+            lap("index create (buffers)");
             if (!rc) rc = sa_hip_index_build(c->idx, col.text + t0, len, max_suffix_length);
-            if (!rc) rc = sa_hip_index_set_rows(c->idx, starts.data(), r1 - r0);
+            lap("upload + build");
+            if (!rc) {
+                if (whole) { u64* own = col.row_text_starts; col.row_text_starts = nullptr; rc = set_rows_adopt(c->idx, own, col.num_rows); }
+                else rc = sa_hip_index_set_rows(c->idx, starts.data(), r1 - r0);
+            }
+            lap("row table to the device");
             if (!rc) rc = csv_index_finish(c);
+            lap("file mapping");
         }
     } catch (const std::bad_alloc&) {
         rc = fail(SA_HIP_ENOMEM, "sa_hip_csv_index_create_partitioned: out of host memory");
     }
-    sa_hip_csv_free(&col);
+    // the extracted column (0.9 GB of touched pages at 50M rows) is given back on a thread of its own: unmapping it takes 0.2 s
+    try { std::thread([col]() mutable { sa_hip_csv_free(&col); }).detach(); } catch (...) { sa_hip_csv_free(&col); }
+    memset(&col, 0, sizeof col);
+    lap("free the extracted column");
     sa_hip_csv_index** arr = rc ? nullptr : static_cast<sa_hip_csv_index**>(malloc((parts.size() ? parts.size() : 1) * sizeof(sa_hip_csv_index*)));
     if (!rc && !arr) rc = fail(SA_HIP_ENOMEM, "sa_hip_csv_index_create_partitioned: out of host memory");
     if (rc) { for (sa_hip_csv_index* c : parts) sa_hip_csv_index_destroy(c); return rc; }

@@ -54,7 +54,8 @@ static int check_csv(const char* dir) {
         free(s);
     }
     // hits -> distinct rows over a fake suffix array: every position of the column, in order
-    std::vector<u64> starts(ref.row_text_starts, ref.row_text_starts + ref.num_rows);
+    HostU64Array starts;   // (what the handle keeps: copied here, adopted from the extractor by the CSV index)
+    starts.assign(ref.row_text_starts, ref.row_text_starts + ref.num_rows);
     std::vector<u32> fake((size_t)ref.text_len);
     for (size_t i = 0; i < fake.size(); ++i) fake[i] = (u32)((i * 7919u) % fake.size());
     auto fetch = [&](u64 pos, u64 count, u32* out) { memcpy(out, fake.data() + pos, (size_t)count * 4); return 0; };
