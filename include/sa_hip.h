@@ -281,6 +281,12 @@ int sa_hip_csv_index_adopt(sa_hip_csv_index** out, const char* csv_file, const u
                            const char* column_names, uint32_t num_columns, uint32_t column_index, uint32_t max_suffix_length,
                            int device);
 void sa_hip_csv_index_destroy(sa_hip_csv_index* c);
+/* The same rows without the copies: row_ptrs[i] points INTO the index's read-only mapping of the CSV file (row_lens[i] bytes, line
+ * terminator excluded, NOT NUL-terminated), valid until the index is destroyed; at most k rows, *num_matches = how many.  New
+ * surface (the reference's interface mallocs every record, engine.c:1382): what a binding uses when it builds its own objects
+ * from the bytes anyway. */
+int sa_hip_get_matching_row_spans_file(sa_hip_csv_index* c, const char* substring, uint32_t k, const char** row_ptrs,
+                                       uint32_t* row_lens, uint32_t* num_matches);
 /* A column of more than `partition_bytes` (0 or > 2^32 - 2: 2^32 - 2) bytes as several independent indexes of WHOLE rows over
  * the same file: the reference's partitions (engine.c:1437-1481 cuts the FILE every 2 GiB; suffix_array.pyx:221-247 answers
  * from the partitions one after the other).  *out_parts: malloc'ed array of *num_parts handles (>= 1; each is destroyed with

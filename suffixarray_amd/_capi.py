@@ -27,7 +27,7 @@ EXPORTS = [
     "sa_hip_index_get_freq", "sa_hip_query_batch", "sa_hip_query_batch_device", "sa_hip_query_batch_device_fixed",
     "sa_hip_index_get_sa_range", "sa_hip_index_query_hits", "sa_hip_index_sync", "sa_hip_index_verify", "sa_hip_index_build_stats",
     "sa_hip_index_set_rows", "sa_hip_index_query_rows", "sa_hip_index_query_rows_batch", "sa_hip_index_rows_for_range", "sa_hip_csv_index_copy_rows", "sa_hip_index_get_text", "sa_hip_csv_index_create", "sa_hip_csv_index_adopt",
-    "sa_hip_csv_index_destroy", "sa_hip_csv_index_create_partitioned", "sa_hip_csv_index_free_parts", "sa_hip_csv_index_handle", "sa_hip_csv_index_num_rows", "sa_hip_csv_index_num_columns",
+    "sa_hip_get_matching_row_spans_file", "sa_hip_csv_index_destroy", "sa_hip_csv_index_create_partitioned", "sa_hip_csv_index_free_parts", "sa_hip_csv_index_handle", "sa_hip_csv_index_num_rows", "sa_hip_csv_index_num_columns",
     "sa_hip_csv_index_column_index", "sa_hip_csv_index_column_name", "sa_hip_csv_index_row_tables",
     "sa_hip_get_substring_positions_file", "sa_hip_get_matching_records_file", "sa_hip_get_matching_records", "sa_hip_free_records",
     "sa_hip_init_suffix_array_byte_idxs", "sa_hip_free_suffix_array", "sa_hip_write_suffix_array", "sa_hip_read_suffix_array",
@@ -233,6 +233,8 @@ def lib():
     L.sa_hip_csv_index_adopt.argtypes = [C.POINTER(vp), C.c_char_p, vp, vp, u64, vp, vp, u64, C.c_char_p, u32, u32, u32, C.c_int]
     L.sa_hip_csv_index_destroy.restype = None
     L.sa_hip_csv_index_destroy.argtypes = [vp]
+    L.sa_hip_get_matching_row_spans_file.restype = C.c_int
+    L.sa_hip_get_matching_row_spans_file.argtypes = [vp, C.c_char_p, u32, C.POINTER(C.c_char_p), C.POINTER(u32), C.POINTER(u32)]
     L.sa_hip_csv_index_create_partitioned.restype = C.c_int
     L.sa_hip_csv_index_create_partitioned.argtypes = [C.POINTER(C.POINTER(vp)), C.POINTER(u32), C.c_char_p, C.c_char_p, u32, C.c_int, u64]
     L.sa_hip_csv_index_free_parts.restype = None

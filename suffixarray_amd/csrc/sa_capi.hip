@@ -1325,6 +1325,29 @@ int sa_hip_get_matching_records_file(sa_hip_csv_index* c, const char* substring,
     return 0;
 }
 
+int sa_hip_get_matching_row_spans_file(sa_hip_csv_index* c, const char* substring, uint32_t k, const char** row_ptrs,
+                                       uint32_t* row_lens, uint32_t* num_matches) {
+    if (!c || !c->idx || !substring || !num_matches || (k && (!row_ptrs || !row_lens))) return fail(SA_HIP_EINVAL, "sa_hip_get_matching_row_spans_file: NULL argument");
+    *num_matches = 0;
+    const u32 want = (u32)std::min<u64>(k, sa_hip_csv_index_num_rows(c));
+    if (want == 0) return 0;
+    try {
+        std::vector<u64> rows((size_t)want);
+        u32 n = 0;
+        int rc = sa_hip_index_query_rows(c->idx, reinterpret_cast<const uint8_t*>(substring), strlen(substring), want, rows.data(), &n, nullptr);
+        if (rc) return rc;
+        for (u32 i = 0; i < n; ++i) {
+            const u64 r = rows[i];
+            u64 b = c->row_file_offsets[r], e = c->row_file_offsets[r + 1];
+            while (e > b && (c->map[e - 1] == '\n' || c->map[e - 1] == '\r')) --e;
+            row_ptrs[i] = reinterpret_cast<const char*>(c->map + b);
+            row_lens[i] = (u32)std::min<u64>(e - b, 0xFFFFFFFFull);
+        }
+        *num_matches = n;
+    } catch (const std::bad_alloc&) { return fail(SA_HIP_ENOMEM, "sa_hip_get_matching_row_spans_file: out of host memory"); }
+    return 0;
+}
+
 uint32_t sa_hip_get_matching_records(const char* str, const sa_hip_SuffixArray_struct* s, const char* substring, uint32_t k,
                                      char** matching_records) {
     if (!str || !s || !substring || (!matching_records && k) || (!s->suffix_array && s->n)) { fail(SA_HIP_EINVAL, "sa_hip_get_matching_records: NULL argument"); return 0; }

@@ -69,6 +69,8 @@ cdef extern from "sa_hip.h":
     int sa_hip_get_matching_records_file(sa_hip_csv_index* c, const char* substring, uint32_t k, char** matching_records,
                                          uint32_t* num_matches) nogil
     int sa_hip_csv_index_copy_rows(sa_hip_csv_index* c, const uint64_t* row_ids, uint32_t n, char** records) nogil
+    int sa_hip_get_matching_row_spans_file(sa_hip_csv_index* c, const char* substring, uint32_t k, const char** row_ptrs,
+                                           uint32_t* row_lens, uint32_t* num_matches) nogil
     const char* sa_hip_last_error()
 
 
@@ -87,6 +89,36 @@ cdef _check(int rc):
         if rc == -1 and ("column not found" in msg or "cannot open" in msg or "empty CSV" in msg):
             raise ValueError(msg)
         raise RuntimeError("libsa_hip error %d: %s" % (rc, msg))
+
+
+cdef list _shape_spans(list columns, const char** ptrs, const uint32_t* lens, uint32_t n):
+    """_shape_rows over (pointer, length) spans of the mapped file: no per-row malloc / copy / strlen / free."""
+    cdef list out = []
+    cdef Py_ssize_t ncol = len(columns), c
+    cdef uint32_t i
+    cdef const char* p
+    cdef const char* e
+    cdef const char* q
+    cdef dict d
+    for i in range(n):
+        p = ptrs[i]
+        e = p + lens[i]
+        if memchr(p, 34, lens[i]) != NULL:
+            rec = next(_csv.reader(_io.StringIO(p[:lens[i]].decode("utf-8", "replace"))))
+            out.append(dict(zip(columns, rec)))
+            continue
+        d = {}
+        c = 0
+        while c < ncol:
+            q = <const char*>memchr(p, 44, e - p)
+            if q == NULL:
+                d[columns[c]] = PyUnicode_DecodeUTF8(p, e - p, "replace")
+                break
+            d[columns[c]] = PyUnicode_DecodeUTF8(p, q - p, "replace")
+            p = q + 1
+            c += 1
+        out.append(d)
+    return out
 
 
 cdef list _shape_rows(list columns, char** recs, uint32_t n):
@@ -376,21 +408,25 @@ cdef class SuffixArray:
         cdef int rc
         cdef uint32_t i
         cdef char** recs
+        cdef const char** spans
+        cdef uint32_t* lens
         cdef uint64_t[::1] rv
         if self._mode == "csv" and b"\0" not in pat:
-            # the reference's own call, one level down (pyx:224-232 -> get_matching_records_file)
-            recs = <char**>malloc(kk * sizeof(char*))
-            if recs == NULL:
+            # the reference's own call (pyx:224-232 -> get_matching_records_file) in its zero-copy form: the dicts are built straight
+            # from the rows' bytes in the mapped file (sa_hip_get_matching_records_file mallocs every row for a C caller to free)
+            spans = <const char**>malloc(kk * sizeof(char*))
+            lens = <uint32_t*>malloc(kk * sizeof(uint32_t))
+            if spans == NULL or lens == NULL:
+                free(spans); free(lens)
                 raise MemoryError()
             with nogil:
-                rc = sa_hip_get_matching_records_file(self._csv, pp, kk, recs, &n)
+                rc = sa_hip_get_matching_row_spans_file(self._csv, pp, kk, spans, lens, &n)
             try:
                 _check(rc)
-                return _shape_rows(self.columns, recs, n)
+                return _shape_spans(self.columns, spans, lens, n)
             finally:
-                for i in range(n):
-                    free(recs[i])
-                free(recs)
+                free(spans)
+                free(lens)
         rows = np.empty(kk, dtype=np.uint64)
         rv = rows
         with nogil:
