@@ -1143,6 +1143,22 @@ int sa_hip_csv_index_create(sa_hip_csv_index** out, const char* csv_file, const 
     return 0;
 }
 
+// one helper thread at a time gives large host buffers back (joined before the next one starts and when the library is unloaded:
+// never detached)
+namespace {
+struct BackgroundFree {
+    std::thread t;
+    std::mutex m;
+    void run(sa_hip_csv_column col) {
+        std::lock_guard<std::mutex> g(m);
+        if (t.joinable()) t.join();
+        try { t = std::thread([col]() mutable { csv_free(&col); }); } catch (...) { csv_free(&col); }
+    }
+    ~BackgroundFree() { if (t.joinable()) t.join(); }
+};
+BackgroundFree g_bgfree;
+}  // namespace
+
 // The reference cuts a CSV file into 2 GiB partitions, one suffix array each (engine.c:1437-1481), and answers a query from
 // the partitions one after the other (suffix_array.pyx:221-247).  Here one index holds up to 2^32 - 2 COLUMN bytes whatever
 // the file's size; a column beyond `partition_bytes` is cut at ROW boundaries (no match is lost at a cut) into several
@@ -1223,7 +1239,7 @@ int sa_hip_csv_index_create_partitioned(sa_hip_csv_index*** out_parts, uint32_t*
         rc = fail(SA_HIP_ENOMEM, "sa_hip_csv_index_create_partitioned: out of host memory");
     }
     // the extracted column (0.9 GB of touched pages at 50M rows) is given back on a thread of its own: unmapping it takes 0.2 s
-    try { std::thread([col]() mutable { sa_hip_csv_free(&col); }).detach(); } catch (...) { sa_hip_csv_free(&col); }
+    g_bgfree.run(col);
     memset(&col, 0, sizeof col);
     lap("free the extracted column");
     sa_hip_csv_index** arr = rc ? nullptr : static_cast<sa_hip_csv_index**>(malloc((parts.size() ? parts.size() : 1) * sizeof(sa_hip_csv_index*)));
