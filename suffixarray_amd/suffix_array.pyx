@@ -264,6 +264,19 @@ cdef class SuffixArray:
             except Exception:
                 raise ValueError("Documents must be a list of strings")
         self._documents = documents
+        # ASCII documents without embedded newlines (the usual case): ONE join + encode, the row starts from the newline positions
+        # -- per-document encode() and len() calls were 0.4 s of a 0.5 s construction for 5M short documents (20 ms on the device)
+        try:
+            joined = "\n".join(documents) if documents else None
+        except TypeError:
+            joined = None
+        if joined is not None and len(joined) <= self._partition_bytes and joined.isascii() and joined.count("\n") == len(documents) - 1:
+            raw = joined.encode("ascii")
+            nl = np.flatnonzero(np.frombuffer(raw, dtype=np.uint8) == 10)
+            starts = np.concatenate([np.zeros(1, np.int64), nl + 1]).astype(np.uint64)
+            self._build_documents(ascii_lower(raw), starts, None)
+            self._mode = "documents"
+            return
         encoded = [d.encode("utf-8") for d in documents]
         lens = np.fromiter((len(e) for e in encoded), dtype=np.int64, count=len(encoded))
         if len(encoded) and int(lens.sum()) + len(encoded) - 1 > self._partition_bytes:
