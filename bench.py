@@ -70,7 +70,7 @@ def committed_pmc(name, n, kernel):
     return j
 
 
-def cpu_baseline(text, q_buf, q_off, gpu_sa64, one_thread_n):
+def cpu_baseline(text, q_buf, q_off, gpu_sa64, one_thread_n, one_run=False):
     """The reference's libsais64_omp (oracle/_ref, compiled from the reference's own sources) on the SAME text at
     full size, all usable host cores, best of two runs; the 1-thread libsais figure (the configuration the
     reference's Makefile builds, Makefile:2-5) on a prefix; the oracle's OpenMP restatement of
@@ -92,7 +92,7 @@ def cpu_baseline(text, q_buf, q_off, gpu_sa64, one_thread_n):
             rc = ref.libsais64_into(text, sa64, threads)
             runs.append(time.perf_counter() - t0)
             assert rc == 0
-            if runs[-1] > 40.0:
+            if runs[-1] > 40.0 or one_run:
                 break
         dt = min(runs)
         out.update(kind="reference", value=n / dt, unit="chars/s", cores=threads,
@@ -129,6 +129,50 @@ def cpu_baseline(text, q_buf, q_off, gpu_sa64, one_thread_n):
     out["queries_per_s"] = nq / dq
     out["query_sample"] = f"{nq:,} of the same 16-byte patterns over the SA of the {text.size:,}-char text, {orc.threads_used} threads: {dq:.2f} s"
     return out, equal
+
+
+def d2_words_1e9(_capi, synth, torch, dev, device, n=1_000_000_000, with_cpu=True):
+    """SURVEY 8(d)'s realistic text at the HEADLINE size: D2 words, N = 1e9, the 64-bit build (u32 device build + int64[N] in
+    libsais64 layout, device resident) -- the input on which the pipeline needs its group finisher and refinement rounds (D1
+    needs none).  Verified on the device and, with the CPU baseline, compared with the reference's libsais64_omp output."""
+    t0 = time.perf_counter()
+    text = synth.d2_words_parts(n)
+    gen_s = time.perf_counter() - t0
+    sa64_t = torch.empty(n, dtype=torch.int64, device=dev)
+    with _capi.DeviceIndex(n, device) as idx:
+        idx.build(text)
+        tdev = idx.text_dev
+        ms = []
+        for _ in range(3):
+            idx.build_device64(tdev, n, sa64_t.data_ptr(), 0)
+            ms.append(idx.build_stats()["total_ms"])
+        st = idx.build_stats()
+        out = {"n_chars": n, "text": "synth.d2_words_parts: Zipf(1.0) over one 50 000-word vocabulary, 16 independently drawn parts", "text_gen_s": gen_s,
+               "build_ms": min(ms), "chars_per_s": n / (min(ms) / 1e3), "verify_violations": idx.verify(),
+               "output": "u32 suffix array + int64[N] libsais64 layout, both device resident",
+               **{k: st[k] for k in ("initial_chars", "rounds", "chunk_rounds", "doubling_rounds", "active_total", "finisher_runs", "finisher_records",
+                                     "finisher_resolved", "narrow48", "widen_fused", "final_depth")}}
+        sa32 = idx.sa_u32()
+    gpu64 = sa64_t.cpu().numpy()
+    del sa64_t
+    out["sa64_equals_sa32"] = bool(np.array_equal(gpu64, sa32))
+    del sa32
+    if with_cpu:
+        from oracle.oracle import Ref
+        if Ref.available():
+            cores = usable_cpus()
+            threads = int(os.environ.get("OMP_NUM_THREADS", cores))
+            ref64 = np.zeros(n, dtype=np.int64)
+            t0 = time.perf_counter()
+            rc = Ref().libsais64_into(text, ref64, threads)
+            dt = time.perf_counter() - t0
+            assert rc == 0
+            out["sa64_equals_reference_libsais64"] = bool(np.array_equal(gpu64, ref64))
+            out["cpu_reference"] = {"kind": "reference", "value": n / dt, "unit": "chars/s", "cores": threads,
+                                    "sample": f"libsais64_omp(threads={threads}) on the whole D2 text, one run: {dt:.2f} s"}
+            del ref64
+    out["ok"] = bool(out["verify_violations"] == 0 and out["sa64_equals_sa32"] and out.get("sa64_equals_reference_libsais64", True))
+    return out
 
 
 def secondary_builds(_capi, synth, device):
@@ -200,7 +244,12 @@ def config5_csv(_capi, rows=50_000_000, budget_s=12.0):
                "query_records": {"samples": int(lat.size), "mean_us": float(lat.mean()), "median_us": float(np.median(lat)),
                                  "mean_results": float(np.mean(nres)), "k": 1000,
                                  "protocol": "tests/test.py:99-141 (sampled names, upper-cased, perf_counter per query)"}}
+        # the column itself (one name per '\n'-terminated row) feeds the two measurements below
+        col = idx.text()
+        out["names_batch_1e6"] = names_batch(idx, col, rng)
         s.close()
+        del s, idx
+        out["documents_5M"] = documents_protocol(col, rng)
         return out
     finally:
         try:
@@ -208,6 +257,63 @@ def config5_csv(_capi, rows=50_000_000, budget_s=12.0):
             os.rmdir(tmp)
         except OSError:
             pass
+
+
+def names_batch(idx, col, rng, q=1_000_000):
+    """The reference's real query load -- names that occur (tests/test.py:103-127) -- as ONE batch: q rows sampled from the
+    column, searched by one launch (sa_hip_query_batch: host patterns in, ranges out); kernel time from the library's events."""
+    ends = np.flatnonzero(col == 10)
+    pick = np.sort(rng.integers(1, ends.size, q))
+    a, b = ends[pick - 1] + 1, ends[pick]
+    keep = b > a
+    a, b = a[keep], b[keep]
+    lens = (b - a).astype(np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    src = np.repeat(a - off[:-1].astype(np.int64), lens.astype(np.int64)) + np.arange(int(off[-1]), dtype=np.int64)
+    buf = col[src]
+    ms = []
+    for _ in range(4):
+        res = idx.query_batch((buf, off))
+        ms.append(idx.query_stats()["kernel_ms"])
+    cnt = ((res["second"].astype(np.int64) - res["first"].astype(np.int64) + 1) & 0xFFFFFFFF)
+    cnt[res["first"] == 0xFFFFFFFF] = 0
+    best = min(ms[1:])
+    return {"queries": int(a.size), "mean_pattern_len": float(lens.mean()), "kernel_ms": best, "queries_per_s": a.size / (best / 1e3),
+            "hit_rate": float((cnt > 0).mean()), "mean_hits": float(cnt.mean()), "median_hits": float(np.median(cnt)),
+            "note": "every pattern is a whole name of the column (all hit; patterns longer than the key go to SA + text); kernel time, patterns resident"}
+
+
+def documents_protocol(col, rng, docs_n=5_000_000, budget_s=10.0):
+    """tests/test.py:59-96, the documents constructor: the (upper-cased) company names as a document LIST, construction
+    seconds, 10 000 sampled documents as queries with perf_counter around each query_records, mean / median microseconds
+    and the mean number of results."""
+    from suffixarray_amd import SuffixArray
+    ends = np.flatnonzero(col == 10)
+    cut = int(ends[min(docs_n, ends.size) - 1]) + 1
+    docs = col[:cut].tobytes().decode("latin-1").upper().split("\n")[:-1]
+    del ends
+    t0 = time.perf_counter()
+    s = SuffixArray(documents=docs, max_suffix_length=32)
+    t_index = time.perf_counter() - t0
+    st = s._index.build_stats()
+    sample = [docs[i] for i in rng.integers(0, len(docs), 10_000)]
+    lat, nres = [], []
+    t_all = time.perf_counter()
+    for q in sample:
+        t0 = time.perf_counter()
+        r = s.query_records(q)
+        lat.append((time.perf_counter() - t0) * 1e6)
+        nres.append(len(r))
+        if time.perf_counter() - t_all > budget_s:
+            break
+    lat = np.array(lat)
+    out = {"documents": len(docs), "n_chars": int(st["n"]), "max_suffix_length": 32, "construction_seconds": t_index,
+           "device_build_ms": st["total_ms"],
+           "query_records": {"samples": int(lat.size), "mean_us": float(lat.mean()), "median_us": float(np.median(lat)),
+                             "mean_results": float(np.mean(nres)), "k": 1000,
+                             "protocol": "tests/test.py:59-96 (document list, sampled documents upper-cased, perf_counter per query)"}}
+    s.close()
+    return out
 
 
 def _csv_reader(lines):
@@ -227,11 +333,16 @@ def main():
     ap.add_argument("--cpu-one-thread-chars", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-words-1e9", action="store_true", help="skip secondary.d2_words_1e9 (D2 words at N = 1e9, 64-bit build + the reference's libsais64_omp)")
     ap.add_argument("--offsets-api", action="store_true", help="query through sa_hip_query_batch_device (offsets array) instead of the fixed-length entry")
     ap.add_argument("--separate-widen", action="store_true", help="int64 output by a widening pass after the build (A/B against the fused form)")
     ap.add_argument("--dist-chunks", type=int, default=4, help="pieces a rank's slice is searched and gathered in (pipelined); at most this many, none under 1e6 patterns")
     ap.add_argument("--dist-min-chunk", type=int, default=1_000_000, help="patterns a pipelined piece carries at least")
-    ap.add_argument("--dist-mode", choices=("all_gather", "gather_to_root"), default="all_gather")
+    ap.add_argument("--dist-mode", choices=("all_gather", "gather_to_root", "sharded_rows"), default="all_gather",
+                    help="all_gather / gather_to_root: config 4 as written (the 8-byte ranges of the whole batch land on every rank / on rank 0); "
+                         "sharded_rows: the ranges stay on the rank that found them, every rank materialises the row ids of ITS slice "
+                         "(sa_hip_index_query_rows_batch), only per-rank counts are reduced -- the mode whose rate can scale with the ranks")
+    ap.add_argument("--rows-k", type=int, default=16, help="sharded_rows: distinct rows returned per query at most")
     ap.add_argument("--dump", default=None, help="config 4: write the gathered ranges (+ the SA for N <= 1e8) to this .npz (tests)")
     ap.add_argument("--exercise-dist", action="store_true",
                     help="run the multi-GPU path (RCCL init, index broadcast, sharded batch, all-gather) at world size 1")
@@ -317,6 +428,7 @@ def run_single(args, torch, _capi, synth, dev, device):
     hits &= res[:, 0] != 0xFFFFFFFF
     violations = idx.verify()
     gate = {"verify_violations": violations, "query_hit_rate": float(hits.mean())}
+    populations = query_populations(idx, synth, torch, dev, text, Q, m)
 
     total_ms = build_ms + widen_ms
     chars_per_s = N * steps / (total_ms / 1e3)
@@ -399,6 +511,7 @@ def run_single(args, torch, _capi, synth, dev, device):
                   {"fused": False, "bytes_per_launch": 12.0 * N, "avg_launch_ms": widen_ms / steps,
                    "achieved": 12.0 * N * steps / (widen_ms / 1e3) / 1e9 if widen_ms > 0 else None, "unit": "GB/s"}),
         "roofline_query": rq,
+        "query_populations": populations,
         "gate": gate,
     }
     if last.get("narrow_k") and last.get("text_top_pass") and last.get("rounds") == 0:
@@ -424,7 +537,40 @@ def run_single(args, torch, _capi, synth, dev, device):
         del gpu_sa64, text
         line["secondary"] = secondary_builds(_capi, synth, device)
         line["secondary"]["dropin"] = dropin
+        if N >= 1_000_000_000 and not args.no_words_1e9:
+            torch.cuda.empty_cache()
+            line["secondary"]["d2_words_1e9"] = d2_words_1e9(_capi, synth, torch, dev, device, with_cpu=not args.no_cpu_baseline)
+            gate["d2_words_1e9_ok"] = line["secondary"]["d2_words_1e9"]["ok"]
+            gate["ok"] = bool(gate["ok"] and gate["d2_words_1e9_ok"])
     return line
+
+
+def query_populations(idx, synth, torch, dev, text, Q, m):
+    """The two sub-populations of the D1 batch on their own ("keep both sub-populations and report hit rate"): a
+    batch of Q patterns that all HIT (text windows without a newline: directory + key window + SA + text for a pattern longer
+    than the key) and one of Q that all MISS (random strings: most die in the key array).  Kernel time, best of 5."""
+    big_buf, big_off = synth.query_batch(text, 8 * Q, m, seed=7)
+    pats = big_buf.reshape(-1, m)
+    res = idx.query_batch((big_buf, big_off))
+    hit = (((res["second"].astype(np.int64) - res["first"].astype(np.int64) + 1) & 0xFFFFFFFF) > 0) & (res["first"] != 0xFFFFFFFF)
+    out = {}
+    for name, sel in (("hits_only", np.flatnonzero(hit)[:Q]), ("misses_only", np.flatnonzero(~hit)[:Q])):
+        if sel.size == 0:
+            continue
+        p_t = torch.from_numpy(np.concatenate([np.ascontiguousarray(pats[sel]).reshape(-1), np.zeros(64, np.uint8)])).to(dev)
+        o_t = torch.empty(2 * sel.size, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ms = []
+        for _ in range(6):
+            idx.query_batch_device_fixed(p_t.data_ptr(), m, int(sel.size), o_t.data_ptr())
+            idx.sync()
+            ms.append(idx.query_stats()["kernel_ms"])
+        r = o_t.cpu().numpy().view(np.uint32).reshape(-1, 2)
+        h = (((r[:, 1].astype(np.int64) - r[:, 0].astype(np.int64) + 1) & 0xFFFFFFFF) > 0) & (r[:, 0] != 0xFFFFFFFF)
+        best = min(ms[1:])
+        out[name] = {"queries": int(sel.size), "kernel_ms": best, "queries_per_s": sel.size / (best / 1e3), "hit_rate": float(h.mean())}
+        del p_t, o_t
+    return out
 
 
 def dropin_calls(_capi, torch, dev, text, gpu_sa64):
@@ -488,7 +634,7 @@ def dropin_calls(_capi, torch, dev, text, gpu_sa64):
 
 def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
     """BASELINE config 4 (see the module docstring)."""
-    from suffixarray_amd.distributed import ShardedBatch, replicate_index, shard_bounds
+    from suffixarray_amd.distributed import ShardedBatch, replicate_index, shard_bounds, slot_count
     N, Qg, m = args.n, args.queries_global, args.pattern_len
     text = synth.d1_uniform27(N)                     # the same text on every rank: rank 0 indexes it, all draw patterns from it
 
@@ -528,7 +674,11 @@ def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
     q_buf, q_off = synth.query_batch(text, Qg, m, seed=0, lo=lo, hi=hi)
     # a chunk should carry enough patterns to pay for its collective (tens of microseconds of launch + rendezvous each): at most
     # --dist-chunks pieces, none under a million patterns -- 4 pieces at N <= 2, 2 at N = 4, 1 at N = 8 for the default batch
-    chunks = max(1, min(args.dist_chunks, (hi - lo) // max(1, args.dist_min_chunk)))
+    # (from the rank-INDEPENDENT slot count: slices differ by one pattern, and ranks that disagreed on the chunk count would issue
+    #  different numbers of collectives)
+    chunks = max(1, min(args.dist_chunks, slot_count(Qg, world) // max(1, args.dist_min_chunk)))
+    if args.dist_mode == "sharded_rows":
+        return run_sharded_rows(args, torch, dist, synth, rank, world, dev, text, idx, searcher, build_ms, bcast_ms, bcast_bytes, (q_buf, q_off), barrier)
     batch = ShardedBatch(q_buf, q_off, Qg, world, rank, dev, chunks=chunks, mode=args.dist_mode,
                          search_stream=torch.cuda.ExternalStream(searcher.stream, device=dev))
 
@@ -623,6 +773,74 @@ def run_sharded(args, torch, dist, _capi, synth, rank, local_rank, world, dev):
             "replicate_gbps": bcast_bytes / (bcast_ms / 1e3) / 1e9,
             "replicate_note": "layout + text + SA + key array + directory into reserved buffers, SA range check; nothing is rebuilt on the replica "
                               "(sa_hip_index_replica_*); at world size 1 a device-to-device copy stands in for the broadcast",
+            "gate": gate,
+        }
+    if searcher is not idx:
+        searcher.close()
+    idx.close()
+    return line
+
+
+def run_sharded_rows(args, torch, dist, synth, rank, world, dev, text, idx, searcher, build_ms, bcast_ms, bcast_bytes, slice_pats, barrier):
+    """--dist-mode sharded_rows: what a serving deployment does with a replicated index -- nothing of the per-query result
+    crosses xGMI.  Every rank answers ITS slice completely (ranges + the distinct rows that contain each pattern, at most
+    --rows-k per query: one search launch + one rows launch, sa_hip_index_query_rows_batch, host patterns in, host row ids
+    out); one all-reduce of three counters per step is the only collective.  `value` = global queries/s."""
+    N, Qg, m, k = args.n, args.queries_global, args.pattern_len, args.rows_k
+    # rows of the D1 text = its lines; every rank derives the row table from the text it already holds
+    starts = np.concatenate([[0], np.flatnonzero(text == 10).astype(np.uint64) + 1]).astype(np.uint64)
+    if starts[-1] >= N:
+        starts = starts[:-1]
+    searcher.set_rows(starts)
+    if searcher is not idx and rank == 0:
+        idx.set_rows(starts)
+    q_buf, q_off = slice_pats
+    ql = q_off.size - 1
+
+    def step():
+        rows, ranges = searcher.query_rows_batch_raw((q_buf, q_off), k)
+        c = torch.tensor([float(ql), float(rows[1].sum()), float((rows[1] > 0).sum())], dtype=torch.float64, device=dev)
+        dist.all_reduce(c)
+        return rows, ranges, c
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rows, ranges, c = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    totals = c.tolist()
+    line = None
+    if rank == 0:
+        fb, fo = synth.query_batch(text, Qg, m, seed=0)
+        w0 = time.perf_counter()
+        (wr, wc), wranges = idx.query_rows_batch_raw((fb, fo), k)
+        wdt = time.perf_counter() - w0
+        same = bool(int(totals[0]) == Qg and int(totals[1]) == int(wc.sum()) and int(totals[2]) == int((wc > 0).sum()))
+        lo = 0
+        live = np.arange(k)[None, :] < rows[1][:, None]          # row ids beyond a query's count are not written
+        same = same and bool(np.array_equal(ranges["first"], wranges["first"][lo:lo + ql]) and np.array_equal(ranges["second"], wranges["second"][lo:lo + ql])
+                             and np.array_equal(rows[1], wc[lo:lo + ql]) and np.array_equal(rows[0][live], wr[lo:lo + ql][live]))
+        gate = {"sharded_equals_single_gpu": same, "verify_violations": idx.verify(), "rows_found": int(totals[1]),
+                "queries_with_rows": int(totals[2])}
+        gate["ok"] = bool(same and gate["verify_violations"] == 0)
+        line = {
+            "metric": "batched_queries_per_s", "value": Qg * args.steps / dt, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8 text / u32 suffix indices / u32 range pairs / u64 row ids", "data": "synthetic",
+            "config": {"workload": f"sharded_rows: D1 uniform27 text N={N:,} ({starts.size:,} rows), ONE batch of {Qg:,} {m}-byte queries sharded over {world} GPU(s), "
+                                   f"index built on rank 0 and replicated; every rank returns ranges + up to {k} distinct row ids per query of ITS slice to its own host; "
+                                   f"one all-reduce of three counters per step",
+                       "n_chars": N, "queries_global": Qg, "pattern_len": m, "rows_k": k,
+                       "parallelism": f"replicated index, query batch sharded x{world}, results stay sharded (no gather)"},
+            "build_ms": build_ms, "build_chars_per_s": N / (build_ms / 1e3), "replicate_ms": bcast_ms, "replicate_bytes": bcast_bytes,
+            "one_gpu_same_batch": {"queries_per_s": Qg / wdt, "ms_per_step": wdt * 1e3,
+                                   "note": "the whole batch through the same call on rank 0's GPU alone (one run, after the timed loop)"},
             "gate": gate,
         }
     if searcher is not idx:

@@ -138,7 +138,7 @@ int sa_hip_index_load_device(sa_hip_index* idx, const void* T_dev, const void* S
 
 /* Replicas without any rebuilding (no counterpart in the reference).  The query structures of a built
  * index -- text, suffix array, sorted key array, bucket directory -- are plain device buffers; a replica reserves
- * buffers of the same layout, the caller fills them (RCCL broadcast straight into them: sa_hip_comm_broadcast_index,
+ * buffers of the same layout, the caller fills them (RCCL broadcast straight into them: sa_hip_comm_replicate_index,
  * or torch.distributed over the same pointers), and commit makes the replica searchable after range-checking the
  * suffix array and the directory's ends on the device.  Nothing is gathered, sorted or searched on the replica. */
 typedef struct sa_hip_replica_layout {

@@ -409,6 +409,12 @@ class DeviceIndex:
     def sa_dev(self):
         return self._lib.sa_hip_index_sa_dev(self._h)
 
+    def text(self):
+        """The indexed text (n bytes) copied back to the host (CSV mode: the extracted column)."""
+        out = np.empty(max(self.n, 1), dtype=np.uint8)
+        check(self._lib.sa_hip_index_get_text(self._h, out.ctypes.data))
+        return out[:self.n]
+
     def sa_u32(self):
         out = np.empty(max(self.n, 1), dtype=np.uint32)
         check(self._lib.sa_hip_index_get_sa_u32(self._h, out.ctypes.data))
@@ -499,6 +505,20 @@ class DeviceIndex:
             check(self._lib.sa_hip_index_query_rows_batch(self._h, buf.ctypes.data if buf.size else None, off.ctypes.data, q, k,
                                                           rows.ctypes.data, counts.ctypes.data, ranges.ctypes.data))
         return [rows[i, :counts[i]].copy() for i in range(q)], ranges[:q]
+
+    def query_rows_batch_raw(self, patterns, k):
+        """query_rows_batch without the per-query Python list: ((row_ids uint64[Q, k], counts uint32[Q]), ranges)."""
+        buf, off = patterns if isinstance(patterns, tuple) else pack_patterns(patterns)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        q = off.size - 1
+        rows = np.empty((max(q, 1), max(k, 1)), dtype=np.uint64)
+        counts = np.zeros(max(q, 1), dtype=np.uint32)
+        ranges = np.zeros(max(q, 1), dtype=PAIR_DTYPE)
+        if q:
+            check(self._lib.sa_hip_index_query_rows_batch(self._h, buf.ctypes.data if buf.size else None, off.ctypes.data, q, k,
+                                                          rows.ctypes.data, counts.ctypes.data, ranges.ctypes.data))
+        return (rows[:q], counts[:q]), ranges[:q]
 
     def query_batch_device(self, patterns_dev_ptr, offsets_dev_ptr, q, out_dev_ptr):
         check(self._lib.sa_hip_query_batch_device(self._h, patterns_dev_ptr, offsets_dev_ptr, q, out_dev_ptr))

@@ -22,6 +22,7 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -38,8 +39,9 @@ inline RcclApi& rccl_api() {
         a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.handle, "ncclCommDestroy"));
         a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(dlsym(a.handle, "ncclBroadcast"));
         a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.handle, "ncclAllGather"));
+        a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(a.handle, "ncclAllReduce"));
         a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.handle, "ncclGetErrorString"));
-        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.Broadcast && a.AllGather && a.GetErrorString;
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.Broadcast && a.AllGather && a.AllReduce && a.GetErrorString;
         return a;
     }();
     return api;

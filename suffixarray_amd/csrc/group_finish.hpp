@@ -177,6 +177,17 @@ __global__ __launch_bounds__(FIN_BLOCK, FIN_BLOCK == 512 ? 4 : 2) void group_fin
     }
     if (tid == 0) { s_A = cnt; s_G = G0; s_gq[G0] = (u16)cnt; }
     __syncthreads();
+    if (a.debug) {   // totals[16 + c]: records in groups of [2^c, 2^(c+1)) members when the finisher takes them over
+        if (tid < 16) s_whist[tid] = 0;
+        __syncthreads();
+        for (u32 g = tid; g < G0; g += FIN_BLOCK) {
+            const u32 sz = (u32)s_gq[g + 1] - (u32)s_gq[g];
+            atomicAdd(&s_whist[31 - __clz((int)sz)], sz);
+        }
+        sync_lds();
+        if (tid < 16 && s_whist[tid]) atomicAdd(&a.totals[16 + tid], (unsigned long long)s_whist[tid]);
+        __syncthreads();
+    }
 
     u32 h = a.h0, rounds = 0, stall = 0;
     u32 dbg_radix = 0, dbg_slots_r = 0, dbg_slots_c = 0, dbg_act = 0;

@@ -182,7 +182,12 @@ __global__ __launch_bounds__(256) void per_decide_kernel(PerArgs a) {
             // every neighbouring pair (p_j, p_j + d), j <= m - 2, must meet its first mismatch at the same E: E >= p_{m-2} = plast - d
             if (E + a.d >= plast && E < a.n) dec = ((E + a.d >= a.n) || a.text[E + a.d] < a.text[E]) ? 2 : 1;
         }
-        if (lane == 0) a.dec[g] = dec;
+        if (lane == 0) {
+            a.dec[g] = dec;
+            // a group of this difference whose run ends inside it stays tied: out of the histogram, or the next iteration
+            // of the attempt picks the same difference again and repeats the passes over the text for nothing
+            if (!dec && !a.bad[g] && (u64)a.gd[g] == a.d) a.bad[g] = 1;
+        }
     }
 }
 // one thread per list position: the members of a decided group go to the group's SA slots in ascending or descending order

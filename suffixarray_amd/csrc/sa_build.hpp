@@ -1475,7 +1475,7 @@ struct Builder {
                                ntiles, loc_tiles.as<LocTile>());
         }
         unsigned long long* ft = reinterpret_cast<unsigned long long*>(small.as<u8>() + 3840);
-        SA_HIP_CHECK(hipMemsetAsync(ft, 0, 128, stream));
+        SA_HIP_CHECK(hipMemsetAsync(ft, 0, 256, stream));
         SA_HIP_CHECK(hipMemsetAsync(done.p, 0, (size_t)M, stream));   // records of groups too large for a tile stay untouched
         FinArgs a;
         a.text = text.as<u8>(); a.n = n; a.b = b;
@@ -1485,13 +1485,13 @@ struct Builder {
         a.sa = sa; a.gflags = flags.as<u8>(); a.done = done.as<u8>();
         a.res_idx = ridx0.as<u32>(); a.res_fin = fin_flag.as<u8>(); a.totals = ft;
         hipLaunchKernelGGL(group_finish_kernel, dim3(ntiles), dim3(FIN_BLOCK), 0, stream, a, map);
-        unsigned long long ft_host[16] = {0};
-        SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_FT, ft, 128, hipMemcpyDeviceToHost, stream));
+        unsigned long long ft_host[32] = {0};
+        SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_FT, ft, 256, hipMemcpyDeviceToHost, stream));
         const u32 tiles = div_up(M, BLD_TILE);
         hipLaunchKernelGGL(tiny_flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, gid.as<u32>(), done.as<u8>(), M, lf.as<u8>(),
                            counts.as<uint2>());
         if ((rc = scan_counts(tiles, tot))) return rc;   // synchronises: the mailbox holds the finisher's totals
-        memcpy(ft_host, mbox + MB_FT, 128);
+        memcpy(ft_host, mbox + MB_FT, 256);
         stats.finisher_runs += 1;
         stats.finisher_records += ft_host[0];
         stats.finisher_resolved += (u64)M - tot[0];
@@ -1503,6 +1503,11 @@ struct Builder {
         if (debug_rounds && ft_host[6])
             fprintf(stderr, "[sa_hip]   finisher cycles per tile (thread 0, clock64): fetch+keys %llu, counting sort %llu, radix sort %llu, regroup %llu, write-out %llu\n",
                     ft_host[8] / ft_host[6], ft_host[9] / ft_host[6], ft_host[10] / ft_host[6], ft_host[11] / ft_host[6], ft_host[12] / ft_host[6]);
+        if (debug_rounds && ft_host[6]) {
+            fprintf(stderr, "[sa_hip]   records by group size at entry [2^c, 2^(c+1)):");
+            for (int c = 1; c < 13; ++c) fprintf(stderr, " %d:%llu", c, ft_host[16 + c]);
+            fprintf(stderr, "\n");
+        }
         if (tot[0] < M) {
             if (tot[0]) {
                 SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));

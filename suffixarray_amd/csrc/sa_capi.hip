@@ -537,20 +537,38 @@ int sa_hip_comm_replicate_index(sa_hip_comm* c, sa_hip_index* idx, int root, uin
     RcclApi& r = rccl_api();
     int rc = set_device(c->device);
     if (rc) return rc;
-    // the layout first (a small struct through a device bounce buffer), then the four buffers where they lie
-    sa_hip_replica_layout lay;
-    memset(&lay, 0, sizeof lay);
-    if (c->rank == root && (rc = sa_hip_index_replica_layout(idx, &lay))) return rc;
+    // Every fallible LOCAL step comes before a collective and its outcome travels with it, so that all ranks either run all
+    // four buffer broadcasts or all return: (1) the root's layout goes out together with the root's status -- a root without
+    // an index still broadcasts, with the error set; (2) after every rank has reserved (n > capacity, out of memory) the
+    // ranks agree on the worst status by one all-reduce.  A rank that returned early would leave its peers inside
+    // ncclBroadcast for good.
+    struct Wire { int32_t status; int32_t pad; sa_hip_replica_layout lay; } w;
+    memset(&w, 0, sizeof w);
+    int rc_local = 0;
+    if (c->rank == root) { rc_local = sa_hip_index_replica_layout(idx, &w.lay); w.status = rc_local; }
     void* bounce = nullptr;
-    SA_HIP_CHECK(hipMalloc(&bounce, sizeof lay));
+    if (hipMalloc(&bounce, sizeof w + 16) != hipSuccess) {
+        // (no device memory for ~5 KB: the peers cannot be told either; they fail in the broadcast's own error path)
+        return fail(SA_HIP_ENOMEM, "sa_hip_comm_replicate_index: hipMalloc of the bounce buffer");
+    }
+    int32_t* agree = reinterpret_cast<int32_t*>(static_cast<u8*>(bounce) + sizeof w);
     auto body = [&]() -> int {
-        SA_HIP_CHECK(hipMemcpyAsync(bounce, &lay, sizeof lay, hipMemcpyHostToDevice, c->stream));
-        SA_RCCL_CHECK(r.Broadcast(bounce, bounce, sizeof lay, ncclUint8, root, c->comm, c->stream));
-        SA_HIP_CHECK(hipMemcpyAsync(&lay, bounce, sizeof lay, hipMemcpyDeviceToHost, c->stream));
+        SA_HIP_CHECK(hipMemcpyAsync(bounce, &w, sizeof w, hipMemcpyHostToDevice, c->stream));
+        SA_RCCL_CHECK(r.Broadcast(bounce, bounce, sizeof w, ncclUint8, root, c->comm, c->stream));
+        SA_HIP_CHECK(hipMemcpyAsync(&w, bounce, sizeof w, hipMemcpyDeviceToHost, c->stream));
         SA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (w.status != 0)   // the same decision on every rank: nobody enters the buffer broadcasts
+            return (c->rank == root) ? rc_local : fail(w.status, "sa_hip_comm_replicate_index: the root has no index to replicate");
         sa_hip_replica_buffers b;
-        int rc2 = (c->rank == root) ? sa_hip_index_replica_buffers(idx, &b) : sa_hip_index_replica_reserve(idx, &lay, &b);
-        if (rc2) return rc2;
+        memset(&b, 0, sizeof b);
+        rc_local = (c->rank == root) ? sa_hip_index_replica_buffers(idx, &b) : sa_hip_index_replica_reserve(idx, &w.lay, &b);
+        int32_t mine = rc_local, worst = 0;   // error codes are negative: the minimum is the worst
+        SA_HIP_CHECK(hipMemcpyAsync(agree, &mine, 4, hipMemcpyHostToDevice, c->stream));
+        SA_RCCL_CHECK(r.AllReduce(agree, agree, 1, ncclInt32, ncclMin, c->comm, c->stream));
+        SA_HIP_CHECK(hipMemcpyAsync(&worst, agree, 4, hipMemcpyDeviceToHost, c->stream));
+        SA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (worst != 0)
+            return rc_local ? rc_local : fail(worst, "sa_hip_comm_replicate_index: another rank could not provide / reserve its buffers");
         void* ptr[4] = {b.text, b.sa, b.keys, b.dir};
         const u64 len[4] = {b.text_bytes, b.sa_bytes, b.keys_bytes, b.dir_bytes};
         u64 total = 0;
@@ -561,7 +579,7 @@ int sa_hip_comm_replicate_index(sa_hip_comm* c, sa_hip_index* idx, int root, uin
         }
         SA_HIP_CHECK(hipStreamSynchronize(c->stream));
         if (bytes_out) *bytes_out = total;
-        return (c->rank == root) ? 0 : sa_hip_index_replica_commit(idx);
+        return (c->rank == root) ? 0 : sa_hip_index_replica_commit(idx);   // local, after the last collective
     };
     rc = body();
     (void)hipFree(bounce);

@@ -53,15 +53,25 @@ def device_view(ptr, count, dtype, device):
 
 
 def broadcast_index(text_t, sa_t, src=0, group=None):
-    """Replicate plain (uint8 text, int32-viewed SA) tensors from `src` to every rank: the form the gloo test uses
-    (its searcher is the oracle, which needs nothing else).  xGMI is point-to-point, so one large broadcast per
+    """Replicate plain (uint8 text, int32-viewed SA) tensors from `src` to every rank.  Only tests/test_dist_cpu.py uses
+    this form (its searcher is the oracle, which needs nothing but text and SA); bench.py --gpus N and the GPU tests
+    replicate a built index with replicate_index below.  xGMI is point-to-point, so one large broadcast per
     tensor (RCCL pipelines it over the links) -- never per-chunk Python loops."""
     dist.broadcast(text_t, src=src, group=group)
     dist.broadcast(sa_t, src=src, group=group)
     return text_t, sa_t
 
 
-def replicate_index(src_idx, dst_idx, device, src=0, group=None):
+def host_staged_broadcast(t, src=0, group=None):
+    """Transport for replicate_index on a backend that only moves host memory (gloo): the device tensor goes through a
+    host copy on both sides.  tests/test_gpu_dist.py uses it to run two ranks on ONE GPU, which RCCL refuses."""
+    h = t.cpu() if dist.get_rank(group) == src else torch.empty(t.shape, dtype=t.dtype)
+    dist.broadcast(h, src=src, group=group)
+    if dist.get_rank(group) != src:
+        t.copy_(h)
+
+
+def replicate_index(src_idx, dst_idx, device, src=0, group=None, transport=None):
     """Replicate a built device index WITHOUT rebuilding anything on the receiving side (sa_hip_index_replica_*):
     the layout (a small struct) and then text, suffix array, sorted key array and bucket directory are broadcast
     straight out of the builder's buffers into buffers the replica has reserved; commit range-checks the SA.
@@ -69,7 +79,10 @@ def replicate_index(src_idx, dst_idx, device, src=0, group=None):
     src_idx: the built DeviceIndex on rank `src` (None elsewhere).
     dst_idx: the DeviceIndex that becomes a replica (None on a rank that keeps searching src_idx).  On rank `src`
              itself a dst_idx is filled by a device-to-device copy (world size 1 then runs every line a receiving rank runs).
-    Returns (bytes replicated, [broadcast seconds are the caller's to time])."""
+    transport: callable(tensor, src, group) that makes `tensor` (a device tensor, in place) equal to rank src's on every rank;
+               default dist.broadcast (RCCL).
+    Returns the bytes replicated (the broadcast seconds are the caller's to time)."""
+    bcast = transport if transport is not None else (lambda t, src, group: dist.broadcast(t, src=src, group=group))
     from ._capi import ReplicaLayout
     rank = dist.get_rank(group)
     lay = ReplicaLayout()
@@ -77,7 +90,7 @@ def replicate_index(src_idx, dst_idx, device, src=0, group=None):
     if rank == src:
         lay = src_idx.replica_layout()
         lay_t.copy_(torch.frombuffer(bytearray(bytes(lay)), dtype=torch.uint8))
-    dist.broadcast(lay_t, src=src, group=group)
+    bcast(lay_t, src, group)
     if rank != src:
         lay = ReplicaLayout.from_buffer_copy(lay_t.cpu().numpy().tobytes())
     sbufs = src_idx.replica_buffers().items() if rank == src else None     # synchronises the builder's stream
@@ -88,7 +101,7 @@ def replicate_index(src_idx, dst_idx, device, src=0, group=None):
         if nbytes == 0:
             continue
         t = device_view(ptr, nbytes, torch.uint8, device)
-        dist.broadcast(t, src=src, group=group)
+        bcast(t, src, group)
         if rank == src and dbufs is not None:
             device_view(dbufs[i][0], nbytes, torch.uint8, device).copy_(t)
         total += nbytes
@@ -112,8 +125,12 @@ class ShardedBatch:
     stream), or None when search() has completed on return (the CPU test; a searcher that synchronises).
     """
 
-    def __init__(self, patterns, offsets, q, world_size, rank, device, chunks=1, mode="all_gather", search_stream=None):
+    def __init__(self, patterns, offsets, q, world_size, rank, device, chunks=1, mode="all_gather", search_stream=None,
+                 stage_host=False):
         assert mode in ("all_gather", "gather_to_root")
+        # stage_host: the collective moves host copies of the device buffers (a backend that only takes host memory: two gloo
+        # ranks on one GPU in tests/test_gpu_dist.py); synchronises per chunk, so nothing overlaps.
+        self.stage_host = bool(stage_host)
         self.q, self.world, self.rank = int(q), int(world_size), int(rank)
         self.lo, self.hi = shard_bounds(q, world_size, rank)
         assert offsets.size == self.hi - self.lo + 1
@@ -159,7 +176,19 @@ class ShardedBatch:
             if self._done is not None:
                 self._done[c].record(self.search_stream)
                 torch.cuda.current_stream(self.device).wait_event(self._done[c])
-            if self.world > 1 or dist.is_initialized():
+            if self.stage_host:
+                torch.cuda.synchronize(self.device)
+                mine = self.out[c].cpu()
+                if self.mode == "all_gather":
+                    table = torch.empty(self.world, 2 * self.cslots, dtype=torch.int32)
+                    dist.all_gather_into_tensor(table.view(-1), mine, group=group)
+                    self.gathered[c].copy_(table)
+                else:
+                    parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
+                    dist.gather(mine, parts, dst=0, group=group)
+                    if self.rank == 0:
+                        self.gathered[c].copy_(torch.stack(parts))
+            elif self.world > 1 or dist.is_initialized():
                 if self.mode == "all_gather":
                     dist.all_gather_into_tensor(self.gathered[c].view(-1), self.out[c], group=group)
                 else:

@@ -76,6 +76,14 @@ cdef extern from "sa_hip.h":
 
 cdef bytes _LOWER = bytes((c + 32) if 65 <= c <= 90 else c for c in range(256))
 FORMAT_VERSION = 3
+ROWS_BUDGET = 1 << 24   # row ids per slice of query_records_batch (128 MB of ids on the host, 64 MB on the device)
+
+
+def _map_array(path, dtype):
+    """A saved array as a read-only memory map (an empty file as an empty array: mmap refuses length 0)."""
+    if _os.path.getsize(path) == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.memmap(path, dtype=dtype, mode="r")
 
 
 cdef inline bytes ascii_lower(bytes b):
@@ -232,14 +240,16 @@ cdef class SuffixArray:
         return _capi.DeviceIndex.from_handle(<size_t>self._idx, self)
 
     # -- construction -------------------------------------------------------------------------------------------------
-    cdef _build_documents(self, bytes text, object row_starts, object sa):
-        """text: the joined lower-cased documents; sa: None = build, else a saved suffix array to adopt"""
-        cdef const uint8_t* p = <const uint8_t*>(<const char*>text)
+    cdef _build_documents(self, object text, object row_starts, object sa):
+        """text: the joined lower-cased documents (bytes, or any read-only byte buffer: load() hands over a memory-mapped file);
+        sa: None = build, else a saved suffix array to adopt"""
         cdef uint64_t n = len(text)
+        cdef const uint8_t[::1] tview = text if n else b"\0"
+        cdef const uint8_t* p = &tview[0]
         cdef uint32_t L = self._L
         cdef int rc
-        cdef uint64_t[::1] rs
-        cdef uint32_t[::1] sv
+        cdef const uint64_t[::1] rs
+        cdef const uint32_t[::1] sv
         if n > 0xFFFFFFFE:
             raise ValueError("text exceeds 2^32 - 2 bytes (one index per device)")
         self._release()
@@ -479,20 +489,34 @@ cdef class SuffixArray:
         cdef bytes buf = b"".join(pats) + b"\0"
         cdef const uint8_t* bp = <const uint8_t*>(<const char*>buf)
         cdef uint64_t[::1] offv = off
-        rows = np.empty((Q, kk), dtype=np.uint64)
-        counts = np.zeros(Q, dtype=np.uint32)
+        # The library sizes host and device buffers as Q x k row ids: the batch goes through in slices of at most
+        # ROWS_BUDGET ids (k = 1000, the reference protocol's default, times 100 000 patterns would be 0.8 GB of ids here and
+        # 0.4 GB on the device for results that mostly hold a handful of rows), the buffers reused from slice to slice.
+        cdef uint64_t per = max(<uint64_t>1, <uint64_t>ROWS_BUDGET // max(<uint64_t>kk, <uint64_t>1))
+        if per > Q:
+            per = Q
+        rows = np.empty((per, kk), dtype=np.uint64)
+        counts = np.zeros(per, dtype=np.uint32)
+        soff = np.zeros(per + 1, dtype=np.uint64)
         cdef uint64_t[:, ::1] rv = rows
         cdef uint32_t[::1] cv = counts
+        cdef uint64_t[::1] sov = soff
         cdef int rc
-        cdef uint64_t j
-        with nogil:
-            rc = sa_hip_index_query_rows_batch(self._idx, bp, &offv[0], Q, kk, &rv[0, 0], &cv[0], NULL)
-        _check(rc)
-        for j in range(Q):
-            if self._mode == "csv":
-                res[live[j]] = self._csv_rows(&rv[j, 0], cv[j])
-            else:
-                res[live[j]] = [self._documents[int(r)] for r in rows[j, :cv[j]]]
+        cdef uint64_t j, lo = 0, qs, base
+        while lo < Q:
+            qs = min(per, Q - lo)
+            base = offv[lo]
+            for j in range(qs + 1):
+                sov[j] = offv[lo + j] - base
+            with nogil:
+                rc = sa_hip_index_query_rows_batch(self._idx, bp + base, &sov[0], qs, kk, &rv[0, 0], &cv[0], NULL)
+            _check(rc)
+            for j in range(qs):
+                if self._mode == "csv":
+                    res[live[lo + j]] = self._csv_rows(&rv[j, 0], cv[j])
+                else:
+                    res[live[lo + j]] = [self._documents[int(r)] for r in rows[j, :cv[j]]]
+            lo += qs
         return res
 
     # -- persistence (SURVEY.md 8(f)-3; the reference's save / load is half-built: engine.c:1098-1165, commented-out
@@ -555,7 +579,8 @@ cdef class SuffixArray:
         """Re-open a saved index: uploads text + SA (sa_hip_index_load / sa_hip_csv_index_adopt), no construction."""
         with open(_os.path.join(directory, "meta.json")) as f:
             meta = _json.load(f)
-        if meta.get("format") != "suffixarray_amd" or meta.get("version") != FORMAT_VERSION:
+        # version 2 (round 2) is version 3 without the CSV file's identity (csv_size / csv_mtime_ns) and without partitions
+        if meta.get("format") != "suffixarray_amd" or meta.get("version") not in (2, FORMAT_VERSION):
             raise ValueError("not a suffixarray_amd index of a supported version")
         cdef SuffixArray self = cls(max_suffix_length=meta["max_suffix_length"], device=device)
         if meta.get("mode") == "partitioned":
@@ -567,11 +592,13 @@ cdef class SuffixArray:
                 self._documents = [d for p in self._parts for d in (<SuffixArray>p)._documents]
             self._mode = "partitioned"
             return self
-        text = np.fromfile(_os.path.join(directory, "text.u8"), dtype=np.uint8)
-        sa = np.fromfile(_os.path.join(directory, "sa.u32"), dtype=np.uint32)
+        # memory-mapped, read-only: the arrays stream from the page cache into the upload, so an index larger than the host's
+        # free memory re-opens (np.fromfile held text + SA + row tables in anonymous memory: 5 n + 16 rows bytes)
+        text = _map_array(_os.path.join(directory, "text.u8"), np.uint8)
+        sa = _map_array(_os.path.join(directory, "sa.u32"), np.uint32)
         if text.size != meta["n"] or sa.size != meta["n"]:
             raise ValueError("index files are truncated")
-        starts = np.fromfile(_os.path.join(directory, "row_starts.u64"), dtype=np.uint64)
+        starts = _map_array(_os.path.join(directory, "row_starts.u64"), np.uint64)
         if starts.size and (starts[0] != 0 or starts[-1] > meta["n"] or np.any(starts[1:] < starts[:-1])):
             raise ValueError("index files are corrupt (row table)")
         self.columns = meta["columns"]
@@ -580,26 +607,29 @@ cdef class SuffixArray:
                 self._documents = _json.load(f)
             if len(self._documents) != starts.size:
                 raise ValueError("index files are truncated")
-            self._build_documents(text.tobytes(), starts, sa if sa.size else np.zeros(1, np.uint32))
+            self._build_documents(text, starts, sa if sa.size else np.zeros(1, np.uint32))
             self._mode = "documents"
             return self
-        offs = np.fromfile(_os.path.join(directory, "row_file_offsets.u64"), dtype=np.uint64)
+        offs = _map_array(_os.path.join(directory, "row_file_offsets.u64"), np.uint64)
         if offs.size != starts.size + 1:
             raise ValueError("index files are truncated")
         try:
             st = _os.stat(meta["csv_filename"])
         except OSError:
             raise ValueError("the CSV file of this index is gone: " + meta["csv_filename"])
-        if int(st.st_size) != meta.get("csv_size") or int(st.st_mtime_ns) != meta.get("csv_mtime_ns"):
+        if "csv_size" not in meta:
+            import warnings
+            warnings.warn("index saved by format version 2: the CSV file's identity was not recorded and cannot be checked")
+        elif int(st.st_size) != meta.get("csv_size") or int(st.st_mtime_ns) != meta.get("csv_mtime_ns"):
             raise ValueError("the CSV file has changed since the index was saved (size / modification time): rebuild the index")
         cdef bytes fn = _os.fsencode(meta["csv_filename"])
         cdef bytes names = b"".join(c.encode("utf-8") + b"\0" for c in meta["columns"])
         cdef const char* fnp = fn
         cdef const char* namesp = names
-        cdef uint8_t[::1] tv = text if text.size else np.zeros(1, np.uint8)
-        cdef uint32_t[::1] sv = sa if sa.size else np.zeros(1, np.uint32)
-        cdef uint64_t[::1] stv = starts if starts.size else np.zeros(1, np.uint64)
-        cdef uint64_t[::1] ofv = offs
+        cdef const uint8_t[::1] tv = text if text.size else np.zeros(1, np.uint8)
+        cdef const uint32_t[::1] sv = sa if sa.size else np.zeros(1, np.uint32)
+        cdef const uint64_t[::1] stv = starts if starts.size else np.zeros(1, np.uint64)
+        cdef const uint64_t[::1] ofv = offs
         cdef uint64_t n = text.size, rows = starts.size
         cdef uint32_t ncols = len(meta["columns"]), ci = meta["column_index"], L = self._L
         cdef int rc, dev = self.device

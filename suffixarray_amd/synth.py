@@ -55,6 +55,48 @@ def d2_words(n, seed=12345, vocab=50000):
     return out[:n].copy()
 
 
+def _d2_tables(seed, vocab):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(2, 13, vocab)
+    letters = rng.integers(97, 123, int(lens.sum()), dtype=np.uint8)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    w = 1.0 / np.arange(1, vocab + 1)
+    p = w / w.sum()
+    return lens, letters, starts, np.cumsum(p), float((lens * p).sum()) + 1.0
+
+
+def _d2_part(n, tabs, seed, k):
+    lens, letters, starts, cdf, avg = tabs
+    rng = np.random.default_rng([seed, k])
+    nwords = int(n / avg * 1.15) + 64
+    ids = np.searchsorted(cdf, rng.random(nwords)).clip(0, lens.size - 1).astype(np.int32)
+    wl = lens[ids]
+    out = np.full(int((wl + 1).sum()), 32, dtype=np.uint8)
+    pos = np.concatenate([[0], np.cumsum(wl + 1)[:-1]])
+    for j in range(int(lens.max())):
+        m = np.flatnonzero(wl > j)
+        out[pos[m] + j] = letters[starts[ids[m]] + j]
+    idx = np.cumsum(rng.integers(8, 17, nwords // 8 + 2))
+    idx = idx[idx < nwords]
+    out[pos[idx] + wl[idx]] = 10
+    return out[:n]
+
+
+def d2_words_parts(n, seed=12345, vocab=50000, parts=16, threads=None):
+    """D2 at sizes where d2_words (one generator, one thread: ~65 s per 1e9 characters) is too slow for a bench run: the same
+    distribution -- Zipf(1.0) draws from ONE synthetic vocabulary, space separated, a newline every 8..16 words -- drawn as
+    `parts` independent streams (default_rng([seed, k])) by a thread pool and concatenated.  A different text from
+    d2_words(n, seed), the same generator per part."""
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    tabs = _d2_tables(seed, vocab)
+    per = [n // parts + (1 if k < n % parts else 0) for k in range(parts)]
+    workers = threads or max(1, min(parts, len(os.sched_getaffinity(0))))
+    with ThreadPoolExecutor(workers) as ex:
+        outs = list(ex.map(lambda k: _d2_part(per[k], tabs, seed, k), range(parts)))
+    return np.concatenate(outs)
+
+
 def all_same(n, ch=97):
     return np.full(n, ch, dtype=np.uint8)
 

@@ -8,7 +8,7 @@ offsets are 64-bit (the reference truncates to uint32).
 """
 import numpy as np
 
-from .index import _ascii_lower
+from suffixarray_amd.index import _ascii_lower
 
 
 class ColumnText:
@@ -80,7 +80,7 @@ def _parse_rows(data: bytes):
 def extract_column(filename: str, search_column: str) -> ColumnText:
     """Native extractor (libsa_hip.so, csrc/csv_ingest.hpp); extract_column_py is the same state
     machine in Python and serves as its reference in the tests."""
-    from . import _capi
+    from suffixarray_amd import _capi
     try:
         names, text, starts, offs = _capi.csv_extract_column(filename, search_column, copy=False)
     except _capi.SaHipError as e:

@@ -59,6 +59,45 @@ def test_config4_path_world1_child_process(gpu, oracle, tmp_path, mode, chunks, 
         mode, chunks, line["value"] / 1e9, line["search_only_queries_per_s"] / 1e9, line["replicate_ms"], line["replicate_bytes"] / 1e6))
 
 
+@pytest.mark.parametrize("mode,chunks", [("all_gather", 2), ("gather_to_root", 1)])
+def test_replicate_index_two_ranks_one_gpu(gpu, oracle, tmp_path, mode, chunks):
+    """World size 2 on ONE MI355X: two fresh child processes on device 0, backend gloo with host-staged copies as the transport
+    (RCCL refuses two ranks on one GPU).  Rank 1 runs the RECEIVING side of replicate_index -- the layout decoded from the
+    broadcast, replica_reserve, the four buffers received, replica_commit -- from a layout that really crossed a process
+    boundary, then answers its slice (and, alone, the whole batch).  Everything is compared with the oracle here."""
+    n, q, m = 20_000_000, 300_001, 16
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(tmp_path), str(n), str(q), mode, str(chunks)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600))
+        except subprocess.TimeoutExpired:
+            for x in procs:
+                x.kill()
+            raise
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    text = synth.d1_uniform27(n)
+    sa = oracle.sais(text).astype(np.uint32)
+    assert np.array_equal(r0["sa"], sa) and np.array_equal(r1["replica_sa"], sa)
+    assert int(r1["n"][0]) == n and np.array_equal(r1["freq"], np.bincount(text, minlength=256))
+    assert int(r0["moved"][0]) == int(r1["moved"][0]) >= 9 * n
+    fb, fo = synth.query_batch(text, q, m, seed=0)
+    exp = oracle.query_batch(text, sa, 0xFFFFFFFF, (fb, fo))
+    assert np.array_equal(r1["whole_first"], exp["first"]) and np.array_equal(r1["whole_second"], exp["second"])
+    assert np.array_equal(r0["first"], exp["first"]) and np.array_equal(r0["second"], exp["second"])   # the gathered table on rank 0
+    if mode == "all_gather":
+        assert np.array_equal(r1["first"], exp["first"]) and np.array_equal(r1["second"], exp["second"])
+    else:
+        assert "first" not in r1.files
+
+
 def _replicate_locally(gpu, src, n_max):
     """The replica entry points with torch device-to-device copies as the transport (what RCCL does between GPUs)."""
     import torch

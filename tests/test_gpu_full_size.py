@@ -132,6 +132,58 @@ def test_config3_n1e9_properties(gpu, oracle):
             assert bytes(t[sa[nxt]:sa[nxt] + m]) > p
 
 
+def test_d2_words_n1e9_properties(gpu, oracle):
+    """SURVEY 8(d)'s realistic text at the headline size: D2 words, N = 1e9 -- the 10-byte-record sort, the in-LDS group
+    finisher and the global rounds on ~5e8 tied suffixes (D1 needs none of them).  Size-independent properties: the suffix array
+    verified on the device (unique => bit-exact), the int64 copy of a 64-bit build equal to the u32 array, query ranges against
+    the oracle's restatement over the downloaded array, hits and their neighbours against the text."""
+    import torch
+    from suffixarray_amd import synth
+    n, q = 1_000_000_000, 200_000
+    t = synth.d2_words_parts(n)
+    rng = np.random.default_rng(11)
+    pos = rng.integers(0, n - 40, q)
+    lens = rng.integers(1, 33, q)
+    pats = [bytes(t[p:p + l]) for p, l in zip(pos[: q // 2], lens[: q // 2])]
+    pats += [bytes(rng.integers(97, 123, l, dtype=np.uint8)) for l in lens[q // 2:]]          # mostly misses
+    pats = [p.replace(b"\n", b" ") for p in pats]
+    sa64_t = torch.empty(n, dtype=torch.int64, device="cuda:0")
+    with gpu.DeviceIndex(n, 0) as idx:
+        idx.build(t)
+        idx.build_device64(idx.text_dev, n, sa64_t.data_ptr(), 0)
+        st = idx.build_stats()
+        assert st["narrow48"] == 1 and st["finisher_resolved"] > n // 10 and st["rounds"] >= 1, st
+        assert idx.verify() == 0, st
+        got = idx.query_batch(pats)
+        sa = idx.sa_u32()
+    sa64 = sa64_t.cpu().numpy()
+    del sa64_t
+    for lo in range(0, n, 1 << 27):
+        hi = min(n, lo + (1 << 27))
+        assert np.array_equal(sa64[lo:hi], sa[lo:hi].astype(np.int64))
+    del sa64
+    exp = oracle.query_batch(t, sa, 0xFFFFFFFF, pats)
+    assert np.array_equal(got, exp)
+    hits = ((exp["second"].astype(np.int64) - exp["first"].astype(np.int64) + 1) & 0xFFFFFFFF) > 0
+    assert 0.3 < hits.mean() < 0.9
+    for i in rng.integers(0, q, 1500):
+        f, s = int(got["first"][i]), int(got["second"][i])
+        p = pats[i]
+        m = len(p)
+        if f == 0xFFFFFFFF:
+            assert bytes(t[sa[n - 1]:sa[n - 1] + m]) < p
+            continue
+        for slot in range(f, min(s, f + 10) + 1):
+            assert bytes(t[sa[slot]:sa[slot] + m]) == p
+        if f > 0:
+            assert bytes(t[sa[f - 1]:sa[f - 1] + m]) < p
+        nxt = s + 1 if s >= f else f
+        if nxt < n:
+            assert bytes(t[sa[nxt]:sa[nxt] + m]) > p
+    print("D2 words n=1e9: build %.1f ms, k0=%d, rounds %d, active_total %d, finisher resolved %d" % (
+        st["total_ms"], st["initial_chars"], st["rounds"], st["active_total"], st["finisher_resolved"]))
+
+
 def test_long_repeats_67m_many_doubling_rounds(gpu, monkeypatch):
     """A 1 MiB random block repeated 64 times: ~24 refinement rounds over 6.7e7 active records each.
     Regression for a lost-LDS-atomic race (bare s_barrier after ds_add on a loop path, see
@@ -202,7 +254,7 @@ def test_config5_full_size_csv_mode(gpu, oracle, tmp_path):
     hit count equals a memmem count over the extracted column."""
     import time
     from suffixarray_amd import SuffixArray
-    from suffixarray_amd.csv_ingest import extract_column
+    from csv_ingest import extract_column
     rows = 50_000_000
     path = tmp_path / "companies.csv"
     gpu.synth_csv(str(path), rows, 1)

@@ -234,7 +234,7 @@ def test_config5_csv_mode_reduced_scale(gpu, tmp_path):
     """BASELINE config 5 at reduced scale: synthetic company_name CSV, max_suffix_length = 32,
     query_records against a brute-force scan of the column."""
     from suffixarray_amd import SuffixArray
-    from suffixarray_amd.csv_ingest import extract_column
+    from csv_ingest import extract_column
     path = tmp_path / "companies.csv"
     gpu.synth_csv(str(path), 200_000, 11)
     col = extract_column(str(path), "company_name")
@@ -317,7 +317,7 @@ def test_loaded_csv_index_against_the_oracle_and_refusals(gpu, oracle, tmp_path)
     import json
     import shutil
     from suffixarray_amd import SuffixArray
-    from suffixarray_amd.csv_ingest import extract_column
+    from csv_ingest import extract_column
     path = tmp_path / "companies.csv"
     gpu.synth_csv(str(path), 120_000, 3)
     L = 32
@@ -389,7 +389,7 @@ def test_device_rows_equal_host_rows(gpu, monkeypatch):
     path it replaces (records.hpp: distinct_rows over copied SA slabs) -- the same rows in the same order for every k up to
     4096 (both table sizes), single query and batch, ranges of a few million hits in a handful of rows included -- and
     both against a plain scan of the column."""
-    from suffixarray_amd.csv_ingest import extract_column
+    from csv_ingest import extract_column
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "c.csv")

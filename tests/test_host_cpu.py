@@ -202,7 +202,7 @@ def test_pipeline_model_truncated(oracle):
 
 
 def test_csv_native_matches_python_reference(tmp_path, capi):
-    from suffixarray_amd.csv_ingest import extract_column, extract_column_py
+    from csv_ingest import extract_column, extract_column_py
     p = tmp_path / "t.csv"
     p.write_bytes(b'id,name,country\n1,Netflix,US\n2,"Acme, Inc.",US\n\n3,"Multi\nLine ""Q""",DE\r\n4,netflix studios,US\n5,,FR\n6')
     big = tmp_path / "big.csv"
@@ -217,12 +217,31 @@ def test_csv_native_matches_python_reference(tmp_path, capi):
     assert data.startswith(b"id,company_name,country\n") and b'", Inc."' not in data and b', Inc."' in data
 
 
+def test_csv_native_matches_python_reference_1e6_rows(tmp_path, capi, monkeypatch):
+    """The native extractor pinned at a size where its range splitting is really at work (1.2e6 rows of the config-5 generator,
+    ~34 MB: several worker parts, quoted ', Inc.' fields across part boundaries) against the byte-serial Python state machine
+    (tests/csv_ingest.py: extract_column_py).  tests/test_gpu_full_size.py::test_config5_full_size_csv_mode takes its expected
+    column from the native extractor; this is what pins that extractor beyond golden_csv.npz's 10 000 rows."""
+    from csv_ingest import extract_column, extract_column_py
+    big = tmp_path / "big.csv"
+    capi.synth_csv(str(big), 1_200_000, 7)
+    ref = extract_column_py(str(big), "company_name")
+    assert len(ref.text_row_starts) == 1_200_000
+    for threads in ("1", "5", "16"):
+        monkeypatch.setenv("SA_HIP_CSV_THREADS", threads)
+        got = extract_column(str(big), "company_name")
+        assert got.columns == ref.columns
+        assert got.text == ref.text, threads
+        assert np.array_equal(got.text_row_starts, ref.text_row_starts), threads
+        assert np.array_equal(got.row_file_offsets, ref.row_file_offsets), threads
+
+
 def test_csv_native_randomized_against_python_reference(tmp_path, capi, monkeypatch):
     """Random small CSV files built from the pieces that steer the two native paths (rows without a quote character go
     through memchr sweeps, the others through the state machine): bare CR, CRLF, blank lines, rows with fewer fields than
     the wanted column, quoted fields with commas / newlines / doubled quotes, a last row without a terminator; 1 and 3
     worker threads (tiny files give one part; the range splitting is covered by the 20 000-row file above)."""
-    from suffixarray_amd.csv_ingest import extract_column, extract_column_py
+    from csv_ingest import extract_column, extract_column_py
     rng = np.random.default_rng(17)
     atoms = [b"abc", b"X", b"", b"Hello World", b'"q,1"', b'"two\nlines"', b'"say ""hi"""', b'""', b"a b", b"Z9"]
     eols = [b"\n", b"\n", b"\n", b"\r\n", b"\r", b"\n\n", b"\r\n\r\n"]
@@ -248,7 +267,7 @@ def test_csv_native_randomized_against_python_reference(tmp_path, capi, monkeypa
 
 
 def test_csv_ingest(tmp_path):
-    from suffixarray_amd.csv_ingest import extract_column
+    from csv_ingest import extract_column
     p = tmp_path / "c.csv"
     p.write_text('id,name,country\n1,Netflix,US\n2,"Acme, Inc.",US\n3,"Multi\nLine ""Q""",DE\n4,netflix studios,US\n')
     col = extract_column(str(p), "name")
@@ -293,7 +312,7 @@ def test_csv_extractor_against_reference_row_sets(capi, tmp_path):
     construct_truncated_suffix_array_from_csv_partitioned_mmap) for every pattern without a byte below ','."""
     import os
     from conftest import GOLDEN
-    from suffixarray_amd.csv_ingest import extract_column
+    from csv_ingest import extract_column
     g = np.load(os.path.join(GOLDEN, "golden_csv.npz"), allow_pickle=False)
     for name in g["names"]:
         data = bytes(g[f"csv__{name}"])

@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from suffixarray_amd import _capi, SuffixArray
-from suffixarray_amd.csv_ingest import extract_column
+from csv_ingest import extract_column
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
 path = "/tmp/companies_%d.csv" % rows

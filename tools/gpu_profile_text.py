@@ -22,7 +22,7 @@ elif kind == "repeat":
     rng = np.random.default_rng(1)
     t = np.tile(rng.integers(97, 123, 1 << 20, dtype=np.uint8), n // (1 << 20) + 1)[:n].copy()
 elif kind == "names":
-    from suffixarray_amd.csv_ingest import extract_column
+    from csv_ingest import extract_column
     rows = n // 18   # ~18.3 column characters per row
     path = "/tmp/companies_%d.csv" % rows
     _capi.synth_csv(path, rows, 1)
