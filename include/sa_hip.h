@@ -386,7 +386,7 @@ typedef struct sa_hip_build_stats {
     uint32_t widen_fused;        /* 1: the int64 copy of sa_hip_index_build_device64 came out of the sort's last pass       */
     uint32_t narrow48;           /* 1: keys of 41..56 bits sorted as 10-byte records (u32 + u16 key parts + u32 index): kernels [1] =
                                   *    text_top_pass_kernel<512, true>, [2] / [3] = seg48_onesweep_kernel                           */
-    uint32_t pad_;
+    uint32_t lite_flags;         /* 1: the first flags pass wrote no flag array (near-random text: active records staged per tile)  */
     uint64_t period_resolved;    /* suffixes ordered by the periodic-run shortcut (long repeats: period_finish.hpp)              */
 } sa_hip_build_stats;
 int sa_hip_index_build_stats(const sa_hip_index* idx, sa_hip_build_stats* out);

@@ -59,7 +59,7 @@ class BuildStats(C.Structure):
                 ("pass_ms", C.c_double * 4), ("pass_bytes", C.c_uint64 * 4), ("pass_launches", C.c_uint32 * 4),
                 ("text_top_pass", C.c_uint32), ("narrow_k", C.c_uint32), ("widen_ms", C.c_double),
                 ("finisher_records", C.c_uint64), ("finisher_resolved", C.c_uint64), ("finisher_runs", C.c_uint32),
-                ("widen_fused", C.c_uint32), ("narrow48", C.c_uint32), ("pad_", C.c_uint32),
+                ("widen_fused", C.c_uint32), ("narrow48", C.c_uint32), ("lite_flags", C.c_uint32),
                 ("period_resolved", C.c_uint64)]
 
     def as_dict(self):

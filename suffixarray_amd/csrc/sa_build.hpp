@@ -343,6 +343,182 @@ __global__ __launch_bounds__(BLD_BLOCK) void flags_kernel(const u64* __restrict_
     }
 }
 
+// ---- the first flags pass of a near-random text: active records straight to a per-tile staging area -----------------
+// On the narrow-record plan (keys of <= 40 bits: the text is near-random and a fraction of a percent of the suffixes is still
+// tied) the full pass above writes a flag byte per slot (n bytes) that compact_kernel reads back (n bytes) to find those few
+// records.  Here the pass keeps its flags in registers: head / active bits of a thread's 16 slots as two 16-bit masks, one
+// workgroup scan gives every active slot its place in the tile's staging row (LITE_CAP entries of {slot, suffix, head bit}),
+// and lite_gather_kernel moves the rows to the dense lists once the per-tile counts have been scanned.  No flag array at
+// all: the later phases that mark heads in it (refinement write-backs, doubling) get it from materialise_flags() first --
+// on this plan the tiny-group finisher normally resolves everything and nobody asks.  A tile with more than LITE_CAP
+// active slots (6.25 %: the tiny-group finisher's own limit is M * 16 <= n) raises *overflow and the build repeats the
+// pass in its full form.  The bucket directory is written exactly as above.
+constexpr u32 LITE_CAP = 256;
+struct LiteArgs {
+    const u32* sa;       // suffix per slot (the sort's values)
+    u32* st_pos;         // [tiles][LITE_CAP] slot
+    u32* st_idx;         // [tiles][LITE_CAP] suffix
+    u8* st_head;         // [tiles][LITE_CAP] 1 = first slot of its group
+    u32* overflow;       // set to 1 by a tile with more than LITE_CAP active slots
+};
+__global__ __launch_bounds__(BLD_BLOCK) void flags_lite_kernel(NarrowKeys nk, u32 n, uint2* __restrict__ counts, DirArgs dirargs, LiteArgs o) {
+    constexpr int WAVES = BLD_BLOCK / WAVE;
+    constexpr int STEPS = BLD_ITEMS / 4;
+    static_assert(STEPS == 4, "two packed scan words of two steps each");
+    __shared__ u32 s_w0[WAVES], s_w1[WAVES], s_h[WAVES];
+    __shared__ u32 s_b[257];
+    for (int i = threadIdx.x; i <= 256; i += BLD_BLOCK) s_b[i] = nk.bstart[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 ntiles = (u32)(((u64)n + BLD_TILE - 1) / BLD_TILE);
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const u64 base = (u64)tile * BLD_TILE;
+        u32 bkt;
+        {
+            const u64 j0 = base + (u64)threadIdx.x * 4;
+            const u64 jf = (j0 > 0) ? j0 - 1 : 0;
+            u32 lo = 0, hi = 256;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const u32 mid = (lo + hi) >> 1;
+                if ((u64)s_b[mid] <= jf) lo = mid; else hi = mid;
+            }
+            bkt = lo;
+        }
+        u32 amask = 0, hmask = 0;   // bit 4 * it + e: slot base + it * 1024 + tid * 4 + e is active / a head
+#pragma unroll
+        for (int it = 0; it < STEPS; ++it) {
+            const u64 j0 = base + (u64)it * (BLD_BLOCK * 4) + (u64)threadIdx.x * 4;
+            if (j0 >= n) continue;
+            u32 w[6];
+            if (j0 + 4 <= n) {
+                const uint4 x = *reinterpret_cast<const uint4*>(nk.keys32 + j0);
+                w[1] = x.x; w[2] = x.y; w[3] = x.z; w[4] = x.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[1 + e] = (j0 + e < n) ? nk.keys32[j0 + e] : 0u;
+            }
+            w[0] = (j0 > 0) ? nk.keys32[j0 - 1] : 0u;
+            w[5] = (j0 + 4 < n) ? nk.keys32[j0 + 4] : 0u;
+            u64 k[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                const u64 j = j0 + e - 1;
+                if (j < n && !(e == 0 && j0 == 0)) {
+                    while ((u64)s_b[bkt + 1] <= j) ++bkt;
+                    k[e] = ((u64)bkt << 56) | ((u64)w[e] << nk.lo_shift);
+                } else k[e] = 0ull;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const u64 j = j0 + e;
+                if (j < n) {
+                    const u64 kk = k[1 + e], kprev = k[e];
+                    const bool head = (j == 0) || (kprev != kk);
+                    const bool next_head = (j + 1 == n) || (k[2 + e] != kk);
+                    if (dirargs.dir && head) {
+                        const int ds = 64 - dirargs.dbits;
+                        const u32 bj = (u32)(kk >> ds);
+                        const u32 first = (j == 0) ? 0u : (u32)(kprev >> ds) + 1u;
+                        if (first <= bj) dir_emit(dirargs, first, bj, (u32)j);
+                    }
+                    if (dirargs.dir && j + 1 == n)
+                        dir_emit(dirargs, (u32)(kk >> (64 - dirargs.dbits)) + 1u, 1u << dirargs.dbits, n);
+                    if (!(head && next_head)) {
+                        amask |= 1u << (4 * it + e);
+                        if (head) hmask |= 1u << (4 * it + e);
+                    }
+                }
+            }
+        }
+        // slots of a tile in order: (step, thread, element).  Per step the threads' counts (0..4) are scanned: two steps per
+        // 32-bit word (a step's total is at most 1024)
+        const u32 c0 = (u32)__popc(amask & 0xFu), c1 = (u32)__popc(amask & 0xF0u), c2 = (u32)__popc(amask & 0xF00u), c3 = (u32)__popc(amask & 0xF000u);
+        u32 p0 = c0 | (c1 << 16), p1 = c2 | (c3 << 16), ph = (u32)__popc(hmask);
+        const u32 m0 = p0, m1 = p1;
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) {
+            const u32 t0 = __shfl_up(p0, o2), t1 = __shfl_up(p1, o2);
+            if (lane >= o2) { p0 += t0; p1 += t1; }
+        }
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) ph += __shfl_down(ph, o2);
+        if (lane == 63) { s_w0[wave] = p0; s_w1[wave] = p1; }
+        if (lane == 0) s_h[wave] = ph;
+        __syncthreads();
+        u32 e0 = p0 - m0, e1 = p1 - m1, t0 = 0, t1 = 0, th = 0;   // exclusive inside the wave; totals over the workgroup
+#pragma unroll
+        for (int w2 = 0; w2 < WAVES; ++w2) {
+            if (w2 < wave) { e0 += s_w0[w2]; e1 += s_w1[w2]; }
+            t0 += s_w0[w2]; t1 += s_w1[w2]; th += s_h[w2];
+        }
+        const u32 tot[4] = {t0 & 0xFFFFu, t0 >> 16, t1 & 0xFFFFu, t1 >> 16};
+        const u32 exc[4] = {e0 & 0xFFFFu, e0 >> 16, e1 & 0xFFFFu, e1 >> 16};
+        const u32 ta = tot[0] + tot[1] + tot[2] + tot[3];
+        if (threadIdx.x == 0) {
+            counts[tile] = make_uint2(ta, th);
+            if (ta > LITE_CAP) __hip_atomic_store(o.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (amask && ta <= LITE_CAP) {
+            u32 before = 0;
+#pragma unroll
+            for (int it = 0; it < STEPS; ++it) {
+                u32 r = before + exc[it];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (amask & (1u << (4 * it + e))) {
+                        const u64 j = base + (u64)it * (BLD_BLOCK * 4) + (u64)threadIdx.x * 4 + e;
+                        const u64 at = (u64)tile * LITE_CAP + r;
+                        o.st_pos[at] = (u32)j;
+                        o.st_idx[at] = o.sa[j];
+                        o.st_head[at] = (hmask >> (4 * it + e)) & 1u;
+                        ++r;
+                    }
+                }
+                before += tot[it];
+            }
+        }
+        __syncthreads();   // s_w0 / s_w1 / s_h are reused by the next tile
+    }
+}
+
+// staging rows -> the dense active lists (slot, suffix, dense group id), one wave per tile; offsets = the scanned counts
+__global__ __launch_bounds__(256) void lite_gather_kernel(const uint2* __restrict__ offsets, u32 ntiles, const u32* __restrict__ totals,
+                                                          LiteArgs o, u32* __restrict__ dst_pos, u32* __restrict__ dst_idx,
+                                                          u32* __restrict__ dst_gid) {
+    const int lane = threadIdx.x & 63;
+    const u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const uint2 off = offsets[tile];
+    const u32 end = (tile + 1 < ntiles) ? offsets[tile + 1].x : totals[0];
+    const u32 cnt = end - off.x;   // <= LITE_CAP
+    u32 heads = off.y;
+    const u64 lt = lanemask_lt();
+    for (u32 r0 = 0; r0 < cnt; r0 += 64) {
+        const u32 r = r0 + lane;
+        const bool in = r < cnt;
+        const u64 at = (u64)tile * LITE_CAP + (in ? r : 0);
+        const u32 pos = o.st_pos[at], idx = o.st_idx[at];
+        const bool head = in && o.st_head[at] != 0;
+        const u64 bh = __ballot(head);
+        if (in) {
+            const u32 m = off.x + r;
+            dst_pos[m] = pos;
+            dst_idx[m] = idx;
+            dst_gid[m] = heads + (u32)__popcll(bh & lt) + (head ? 1u : 0u) - 1u;
+        }
+        heads += (u32)__popcll(bh);
+    }
+}
+
+// flags[slot] = 1 for every list element that a finisher has resolved (its slot starts a group of one): what the finisher
+// itself would have stored had the flag array existed then
+__global__ void mark_done_heads_kernel(const u32* __restrict__ apos, const u8* __restrict__ done, u32 m, u8* __restrict__ gflags) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
+        if (done[i]) gflags[apos[i]] = 1;
+}
+
 // exclusive scan of the per-tile {active, heads} pairs in three coalesced steps:
 //   reduce 1024 tiles per workgroup -> scan the partials (one workgroup) -> scan inside each group.
 __device__ __forceinline__ uint2 block_excl_scan_1024(uint2 v, u32* s_a, u32* s_h, uint2* total) {
@@ -629,7 +805,7 @@ __global__ __launch_bounds__(256) void tiny_groups_kernel(const u8* __restrict__
                 const u32 slot = apos[m + k];
                 sa[slot] = v[k];
                 if (sa64) sa64[slot] = (int64_t)v[k];   // (uniform)
-                gflags[slot] = 1;
+                if (gflags) gflags[slot] = 1;   // (uniform; null: no flag array yet, Builder::materialise_flags)
                 done[m + k] = 1;
             }
         }
@@ -945,6 +1121,10 @@ inline u32 stream_grid(u64 work_items, u32 per_block) {
     return (u32)g;
 }
 
+#ifndef SA_FLAGS_GRID
+#define SA_FLAGS_GRID 32768
+#endif
+
 struct Builder {
     hipStream_t stream = nullptr;
     u64 n_max = 0;
@@ -1080,6 +1260,7 @@ struct Builder {
         if (const char* e = diag_env("SA_HIP_WIDE_TEXT_PASS")) wide_text_pass = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_NARROW_K")) narrow_k = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_TINY")) tiny_finisher = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_LITE_FLAGS")) lite_flags = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_LOCAL_ROUNDS")) local_rounds = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_GROUP_FINISH")) group_finish = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_PILOT")) use_pilot = atoi(e) != 0;
@@ -1167,13 +1348,15 @@ struct Builder {
     // the totals and, in the same synchronisation, the sort's device status (check_device_status() looks at this copy:
     // one host round trip per flags pass instead of two)
     DeviceStatus status_seen{};
+    u32 lite_overflow_seen = 0;
     bool status_fresh = false;
     int read_totals(u32* totals_host) {
         static_assert(sizeof(DeviceStatus) <= MB_BIG - MB_STATUS, "mailbox layout");
-        SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_TOTALS, small.as<u8>() + 2048, 2 * sizeof(u32), hipMemcpyDeviceToHost, stream));
+        SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_TOTALS, small.as<u8>() + 2048, 3 * sizeof(u32), hipMemcpyDeviceToHost, stream));   // {active, heads, lite overflow}
         SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_STATUS, radix.dstat, sizeof status_seen, hipMemcpyDeviceToHost, stream));
         SA_HIP_CHECK(hipStreamSynchronize(stream));
         memcpy(totals_host, mbox + MB_TOTALS, 2 * sizeof(u32));
+        memcpy(&lite_overflow_seen, mbox + MB_TOTALS + 2 * sizeof(u32), sizeof(u32));
         memcpy(&status_seen, mbox + MB_STATUS, sizeof status_seen);
         status_fresh = true;
         return 0;
@@ -1247,9 +1430,6 @@ struct Builder {
         // a resident-sized grid that walks the tiles instead of one short-lived workgroup per 4096 slots (244 141 of them at n = 1e9):
         // flags_kernel<true> 2.0 -> 1.55 ms at n = 1e9 with 32768 workgroups (4096 / 8192 / 16384 / 65536: 1.78 / 1.8 / 1.88 / 1.72;
         // 2048, the exact resident count: 2.24), -6 % at 5e8, -18 % at 7.77e8, -9 % at 2e9 (profiles/r03_flags_grid.log)
-#ifndef SA_FLAGS_GRID
-#define SA_FLAGS_GRID 32768
-#endif
         const u32 fgrid = (SA_FLAGS_GRID && tiles > (u32)SA_FLAGS_GRID) ? (u32)SA_FLAGS_GRID : tiles;
         if (nk)
             hipLaunchKernelGGL(flags_kernel<true>, dim3(fgrid), dim3(BLD_BLOCK), 0, stream, (const u64*)nullptr, *nk, cnt, lf_out,
@@ -1262,6 +1442,54 @@ struct Builder {
             dir_ready = true;
         }
         return scan_counts(tiles, totals_host);
+    }
+
+    // The first flags pass in its lite form (flags_lite_kernel): directory + per-tile counts + the active records staged in `stage`
+    // (a buffer of at least ntiles * LITE_CAP * 9 bytes that is free after the sort).  No flag array: flags_valid stays false.
+    bool lite_flags = true;           // SA_HIP_LITE_FLAGS
+    bool flags_valid = true;          // the flag array holds the head bits of the current grouping
+    LiteArgs lite{};
+    NarrowKeys lite_nk{};
+    int flags_lite_pass(const NarrowKeys& nk, u32 cnt, void* stage, u32* totals_host, bool* overflow) {
+        const u32 tiles = div_up(cnt, BLD_TILE);
+        int rc = directory_layout(cnt);
+        if (rc) return rc;
+        DirArgs d{};
+        d.dir = qdir.as<u32>();
+        d.dbits = q_dbits;
+        const u64 nb = (1ull << q_dbits) + 1;
+        d.gaps = reinterpret_cast<uint4*>(qdir.as<u8>() + dir_gap_offset(nb));
+        d.gap_cap = dir_gap_cap(nb);
+        d.gap_count = reinterpret_cast<u32*>(small.as<u8>() + 3584);
+        d.dstat = radix.dstat;
+        SA_HIP_CHECK(hipMemsetAsync(d.gap_count, 0, 4, stream));
+        lite.sa = sa;
+        lite.st_pos = static_cast<u32*>(stage);
+        lite.st_idx = lite.st_pos + (size_t)tiles * LITE_CAP;
+        lite.st_head = reinterpret_cast<u8*>(lite.st_idx + (size_t)tiles * LITE_CAP);
+        lite.overflow = totals_dev() + 2;
+        lite_nk = nk;
+        SA_HIP_CHECK(hipMemsetAsync(lite.overflow, 0, 4, stream));
+        const u32 fgrid = (SA_FLAGS_GRID && tiles > (u32)SA_FLAGS_GRID) ? (u32)SA_FLAGS_GRID : tiles;
+        hipLaunchKernelGGL(flags_lite_kernel, dim3(fgrid), dim3(BLD_BLOCK), 0, stream, nk, cnt, counts.as<uint2>(), d, lite);
+        hipLaunchKernelGGL(dir_fill_kernel, dim3(1024), dim3(256), 0, stream, d);
+        dir_ready = true;
+        if ((rc = scan_counts(tiles, totals_host))) return rc;
+        *overflow = lite_overflow_seen != 0;
+        return 0;
+    }
+    // the flag array after a lite pass, for the phases that mark heads in it: head bits of the initial grouping from the kept key
+    // array (one more pass over it; the counts it also produces are not used)
+    int materialise_flags() {
+        if (flags_valid) return 0;
+        const u32 n32 = (u32)n;
+        const u32 tiles = div_up(n32, BLD_TILE);
+        const u32 fgrid = (SA_FLAGS_GRID && tiles > (u32)SA_FLAGS_GRID) ? (u32)SA_FLAGS_GRID : tiles;
+        hipLaunchKernelGGL(flags_kernel<true>, dim3(fgrid), dim3(BLD_BLOCK), 0, stream, (const u64*)nullptr, lite_nk, n32, flags.as<u8>(),
+                           counts.as<uint2>(), (const u32*)nullptr, (const u32*)nullptr, sa, flags.as<u8>(), DirArgs{});
+        flags_valid = true;
+        SA_HIP_CHECK(hipGetLastError());
+        return 0;
     }
 
     // isa[idx[j]] = head slot of j's group over a domain of cnt elements
@@ -1694,6 +1922,18 @@ struct Builder {
 
         // head flags, active counts
         u32 tot[2];
+        flags_valid = true;
+        bool staged = false;   // the active records sit in the lite pass's staging rows
+        if (keep_narrow && lite_flags) {
+            // near-random text: the lite form of the pass (no flag array; the active records staged in the key buffer the sort
+            // has left free), the full form only when a tile overflows its staging row
+            void* stage = (static_cast<void*>(kres) == keys0.p) ? keys1.p : keys0.p;
+            bool overflow = false;
+            if ((rc = flags_lite_pass(nk, n32, stage, tot, &overflow))) return rc;
+            if (overflow) { if ((rc = flags_and_counts(kres, n32, flags.as<u8>(), nullptr, nullptr, tot, false, &nk))) return rc; }
+            else { flags_valid = false; staged = true; }
+            stats.lite_flags = staged ? 1u : 0u;
+        } else
         if ((rc = flags_and_counts(kres, n32, flags.as<u8>(), nullptr, nullptr, tot, fuse_directory, keep_narrow ? &nk : nullptr))) return rc;
         if ((rc = check_device_status())) return rc;
         u32 M = tot[0], G = tot[1];
@@ -1713,6 +1953,10 @@ struct Builder {
             if ((rc = ridx1.ensure(m0 * 4))) return rc;
             if ((rc = lf.ensure(m0 + 64))) return rc;
             // first compaction: domain = whole SA
+            if (staged)
+                hipLaunchKernelGGL(lite_gather_kernel, dim3(div_up(div_up(n32, BLD_TILE), 4)), dim3(256), 0, stream, (const uint2*)counts.as<uint2>(),
+                                   div_up(n32, BLD_TILE), (const u32*)totals_dev(), lite, apos0.as<u32>(), aidx.as<u32>(), gid.as<u32>());
+            else
             launch_compact(flags.as<u8>(), n32, M, nullptr, sa, apos0.as<u32>(), aidx.as<u32>(), gid.as<u32>());
         }
         const u32 M0 = (M && (L == 0 || h < L)) ? M : 0;   // the first active list (apos0) stays: the slots an int64 copy has to be patched at
@@ -1736,7 +1980,7 @@ struct Builder {
             SA_HIP_CHECK(hipMemsetAsync(done.p, 0, (size_t)M, stream));
             const u32 limit = L ? (u32)(L - h) : TINY_DEPTH;
             hipLaunchKernelGGL(tiny_groups_kernel, dim3(stream_grid(M, 256)), dim3(256), 0, stream, text.as<u8>(), n, aidx.as<u32>(),
-                               gid.as<u32>(), apos_cur, M, h, limit, L ? 1 : 0, sa, flags.as<u8>(), done.as<u8>(),
+                               gid.as<u32>(), apos_cur, M, h, limit, L ? 1 : 0, sa, flags_valid ? flags.as<u8>() : (u8*)nullptr, done.as<u8>(),
                                (sa64_out && stats.widen_fused) ? sa64_out : (int64_t*)nullptr);
             const u32 tiles = div_up(M, BLD_TILE);
             hipLaunchKernelGGL(tiny_flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, gid.as<u32>(), done.as<u8>(), M,
@@ -1744,6 +1988,13 @@ struct Builder {
             if ((rc = scan_counts(tiles, tot))) return rc;
             stats.tiny_resolved = (u64)M - tot[0];
             if (tot[0] == 0 && M == M0) patched_by_tiny = true;   // every slot the int64 copy lacked has just been written in both widths
+            if (tot[0] && !flags_valid) {
+                // something is left for the rounds, which mark heads in the flag array: build it now, with the marks the tiny pass
+                // would have made
+                if ((rc = materialise_flags())) return rc;
+                hipLaunchKernelGGL(mark_done_heads_kernel, dim3(stream_grid(M, 1024)), dim3(256), 0, stream, (const u32*)apos_cur, (const u8*)done.as<u8>(), M,
+                                   flags.as<u8>());
+            }
             if (tot[0] < M) {
                 if (tot[0]) {
                     SA_HIP_CHECK(hipMemcpyAsync(ridx0.p, aidx.p, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
@@ -1755,6 +2006,7 @@ struct Builder {
             }
         }
 
+        if (M && (L == 0 || h < L) && (rc = materialise_flags())) return rc;   // (no-op unless the lite pass ran and no tiny pass followed)
         u32 M_prev = 0;   // active-set size of the previous round (0: none yet)
         while (M && (L == 0 || h < L)) {
             // groups that fit a tile are finished in LDS, whatever their number of rounds; the global round below is for
