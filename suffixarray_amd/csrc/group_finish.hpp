@@ -64,6 +64,7 @@ struct FinArgs {
     u8* done;              // out: per list element 1 = final (its group was resolved and written), 0 = untouched
     u32* res_idx;          // scratch [M]: final suffix per list position
     u8* res_fin;           // scratch [M]: 0 not final, 1 final, 3 final + head of a (sub)group
+    const u64* w0;         // group_finish2_kernel: the 8 text bytes at suffix + h0 of every list position inside a tile (fin_prefetch_kernel)
     unsigned long long* totals;   // [0] records in tiles, [1] records resolved; debug: [2] rounds, [3] radix rounds,
                                   // [4] record slots of the radix rounds, [5] of the counting rounds, [6] tiles, [7] active records over all rounds
     int debug;
@@ -488,5 +489,522 @@ __global__ __launch_bounds__(FIN_BLOCK, FIN_BLOCK == 512 ? 4 : 2) void group_fin
         }
     }
 }
+
+// ---- round 4: the finisher restructured (SA_HIP_FIN_V2=1; NOT the default) ---------------------------------------------------------
+// MEASURED (profiles/r04_finisher_v2_ab.log): bit-identical to the kernel above on every test and no faster -- names 2e8 13.5 vs
+// 13.5 ms, words 1e8 10.1 vs 10.1, the config-5 column 62.6-62.9 vs 61.4 ms.  The counters say why: both kernels issue the same
+// 4 700 vector instructions per wave and tile (the vector ALUs are busy 52 % of the time, the rest is latency two workgroups per
+// CU cannot hide); what the splits save in radix passes the additional cheap rounds spend again (3.1 instead of 2.5 rounds per
+// tile: a split group needs one more round before counting takes over).  Kept behind the switch, with its parity test.
+// What the phase timers of the kernel above said (names, config 5): a round whose tile holds ONE group of more than
+// `count_max` members sends the whole working set through seven radix passes (57 K of a tile's 167 K cycles for 0.9 such
+// rounds per tile, against 10 K for the 2.7 counting rounds), and the deferred write-out re-reads four arrays per record
+// (27 K).  Here:
+//   * every group has its OWN depth (s_gh: characters beyond h0 its members share), so groups of one tile need not advance
+//     in step;
+//   * a group of more than `count_max` members is split apart from the rest, by ONE WAVE and without a workgroup barrier:
+//     the wave finds the common prefix of the group's fetched characters (an OR of differences), ranks the members by the
+//     FIN_SPLIT bits that follow it (stable ballot-match ranking, per-wave counters) and leaves every member's place in
+//     the low bits of its key; the group advances by the whole characters those bits cover (a run of characters every
+//     member shares -- "INTERNATION|AL " -- costs nothing), its parts are ordinary groups from the next round on;
+//   * everything else is ordered by counting as before (a record's place = the members of its group with a smaller key);
+//   * a final record goes straight to its SA slot (one load of the slot, three stores) instead of through per-position
+//     scratch arrays that the end of the tile read back; the rare tile that gives up on a group (24 rounds, or two without
+//     a split: long repeats) RESTORES that group's slots from the list, which still holds what they were.
+// A key is  characters (FIN_FIELD bits, left aligned, masked to the group's kc characters) | compact index (12) | place (12).
+#ifndef SA_FIN_SPLIT_BITS
+#define SA_FIN_SPLIT_BITS 8
+#endif
+constexpr int FIN_SPLIT = SA_FIN_SPLIT_BITS;
+constexpr int FIN_FIELD = 64 - 2 * FIN_POS_BITS;
+constexpr u32 FIN_BIG_CAP = 256;          // groups of more than 16 members per tile: at most CAP / 17
+static_assert(FIN_CAP / 17 < FIN_BIG_CAP && FIN_SPLIT >= 4 && FIN_SPLIT <= 10, "big-group list / split digit");
+
+// The first round's text fetches of every tile as a kernel of their own: one random 8-byte read per record and nothing else,
+// thousands of them in flight per CU -- inside the finisher the same reads are issued by two workgroups per CU that then sit
+// waiting for them (the finisher's time did not move when its sort or its write-out were restructured: it was waiting here).
+// w0[p] = the 8 bytes at text + aidx[p] + h0 for the list positions p inside a tile (groups too large for a tile are skipped).
+__global__ __launch_bounds__(256) void fin_prefetch_kernel(const u8* __restrict__ text, const u32* __restrict__ aidx, const LocTile* __restrict__ tiles,
+                                                           u32 h0, u64* __restrict__ w0) {
+    const LocTile lt = tiles[blockIdx.x];
+    const u32 begin = lt.begin, cnt = lt.local_end - lt.begin;
+    for (u32 p0 = 0; p0 < cnt; p0 += 4 * 256) {
+        u32 iv[4];
+        u64 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 p = p0 + u * 256 + threadIdx.x;
+            iv[u] = aidx[begin + (p < cnt ? p : cnt - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) __builtin_memcpy(&w[u], text + (u64)iv[u] + h0, 8);   // the text is zero padded: in bounds
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 p = p0 + u * 256 + threadIdx.x;
+            if (p < cnt) w0[begin + p] = w[u];
+        }
+    }
+}
+
+__global__ __launch_bounds__(FIN_BLOCK, 4) void group_finish2_kernel(FinArgs a, CodeMap map) {
+    constexpr int WAVES = FIN_BLOCK / WAVE;
+    constexpr int ITEMS = FIN_ITEMS;
+    constexpr u32 CAP = FIN_CAP;
+    constexpr u32 PM = CAP - 1u;
+    __shared__ u64 s_key[CAP];
+    __shared__ u32 s_idx[CAP];            // by compact index: suffix
+    __shared__ u16 s_lgid[CAP];           // by compact index: dense id of the record's group among the active groups
+    __shared__ u32 s_gqp[CAP / 2 + 2];    // by group: compact index of its first record | its position in the tile << 16;  [G] = A
+    __shared__ u8 s_gh[CAP / 2 + 2];      // by group: characters beyond h0 its members are known to share
+    __shared__ u8 s_gsig[CAP / 2 + 2];    // by group: key bits ordered this round (0: all kc characters -- counting, or nothing to split)
+    __shared__ u16 s_hist[WAVES << FIN_SPLIT];
+    __shared__ u16 s_big[FIN_BIG_CAP];
+    __shared__ u32 s_rowa[64], s_rowh[64];
+    __shared__ u32 s_fail[CAP / 32];      // original groups that were not resolved
+    __shared__ u16 s_map[256];
+    __shared__ u32 s_A, s_G, s_nbig, s_anyfail;
+
+    const LocTile lt = a.tiles[blockIdx.x];
+    const u32 cnt = lt.local_end - lt.begin;   // <= CAP
+    if (cnt == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 begin = lt.begin;
+    const u32 gid0 = a.gid[begin];
+
+    if (tid < 256) s_map[tid] = map.code[tid];
+    for (u32 i = tid; i < CAP / 32; i += FIN_BLOCK) s_fail[i] = 0;
+    const u32 G0 = a.gid[begin + cnt - 1] - gid0 + 1;
+    for (u32 g = tid; g <= G0; g += FIN_BLOCK) { s_gh[g] = 0; s_gsig[g] = 0; }
+    {
+        u32 gv[ITEMS], iv[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            u32 p = (u32)tid + (u32)it * FIN_BLOCK;
+            asm("" : "+v"(p));
+            const u32 pc = p < cnt ? p : cnt - 1;
+            gv[it] = a.gid[begin + pc];
+            iv[it] = a.aidx[begin + pc];
+        }
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            u32 p = (u32)tid + (u32)it * FIN_BLOCK;
+            asm("" : "+v"(p));
+            if (p < cnt) {
+                s_idx[p] = iv[it];
+                s_lgid[p] = (u16)(gv[it] - gid0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            u32 p = (u32)tid + (u32)it * FIN_BLOCK;
+            asm("" : "+v"(p));
+            if (p < cnt) {
+                const u32 g = s_lgid[p];
+                if (p == 0 || (u32)s_lgid[p - 1] != g) s_gqp[g] = p | (p << 16);
+            }
+        }
+    }
+    if (tid == 0) { s_A = cnt; s_G = G0; s_gqp[G0] = cnt; s_nbig = 0; s_anyfail = 0; }
+    __syncthreads();
+    if (a.debug) {   // totals[16 + c]: records in groups of [2^c, 2^(c+1)) members when the finisher takes them over
+        u32* hh = reinterpret_cast<u32*>(s_hist);
+        if (tid < 16) hh[tid] = 0;
+        __syncthreads();
+        for (u32 g = tid; g < G0; g += FIN_BLOCK) {
+            const u32 sz = (s_gqp[g + 1] & 0xFFFFu) - (s_gqp[g] & 0xFFFFu);
+            atomicAdd(&hh[31 - __clz((int)sz)], sz);
+        }
+        sync_lds();
+        if (tid < 16 && hh[tid]) atomicAdd(&a.totals[16 + tid], (unsigned long long)hh[tid]);
+        __syncthreads();
+    }
+
+    u32 rounds = 0, stall = 0, resolved = 0;
+    u32 dbg_bigrounds = 0, dbg_bigrec = 0, dbg_slots = 0, dbg_act = 0;
+    long long t_fetch = 0, t_sort = 0, t_perm = 0, t_regroup = 0, t_mark = a.debug ? clock64() : 0;
+    const u32 ub = (u32)a.b;
+    const u32 inv_b = 65536u / ub + 1u;                 // x / b == (x * inv_b) >> 16 for x <= 64, b <= 9
+    u32 kc0 = ((u32)FIN_FIELD * inv_b) >> 16;           // whole characters a key holds (8 bytes are fetched)
+    if (kc0 > 8) kc0 = 8;
+    const u32 cm = a.count_max < 16u ? 16u : a.count_max;
+    u16* wh = s_hist + ((u32)wave << FIN_SPLIT);
+    while (true) {
+        const u32 A = (u32)__builtin_amdgcn_readfirstlane((int)s_A), G = (u32)__builtin_amdgcn_readfirstlane((int)s_G);
+        if (A == 0) break;
+        if (rounds == a.max_rounds || stall >= 2) {
+            // what is still tied goes back to the global path: its ORIGINAL group is restored below
+            for (u32 g = tid; g < G; g += FIN_BLOCK) {
+                const u32 og = a.gid[begin + (s_gqp[g] >> 16)] - gid0;
+                atomicOr(&s_fail[og >> 5], 1u << (og & 31));
+            }
+            if (tid == 0) s_anyfail = 1;
+            break;
+        }
+        const int R = (int)((A + (u32)(WAVE * WAVES) - 1) / (u32)(WAVE * WAVES));   // (no pairing of rows here: odd counts are fine)
+        const u32 woff = (u32)wave * (u32)(WAVE * R) + lane;
+        if (tid < 64) { s_rowa[tid] = 0; s_rowh[tid] = 0; }
+        // the groups that are split apart this round
+        for (u32 g = tid; g < G; g += FIN_BLOCK) {
+            const u32 sz = (s_gqp[g + 1] & 0xFFFFu) - (s_gqp[g] & 0xFFFFu);
+            if (sz > cm) { const u32 slot = atomicAdd(&s_nbig, 1u); s_big[slot] = (u16)g; }
+        }
+        dbg_slots += (u32)(WAVE * WAVES * R);
+        dbg_act += A;
+
+        // 1. keys: the next kc characters of every record, left aligned, above its compact index
+        u64 key[ITEMS];
+        u64 wtext[ITEMS];
+        u32 hsum[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            wtext[j] = 0; hsum[j] = 0;
+            if (j < R) {   // uniform
+                const u32 q = woff + j * WAVE;
+                if (rounds == 0 && a.w0) {   // (uniform) compact index = position in the tile, depth h0: fetched ahead by fin_prefetch_kernel
+                    hsum[j] = a.h0;
+                    wtext[j] = a.w0[begin + (q < A ? q : 0u)];
+                } else {
+                    u64 start = 0;
+                    if (q < A) {
+                        hsum[j] = a.h0 + (u32)s_gh[s_lgid[q]];
+                        start = (u64)s_idx[q] + hsum[j];
+                    }
+                    __builtin_memcpy(&wtext[j], a.text + start, 8);      // the text is zero padded: in bounds
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            key[j] = ~0ull;
+            if (j < R) {
+                const u32 q = woff + j * WAVE;
+                if (q < A) {
+                    const u64 start = (u64)s_idx[q] + hsum[j];       // <= n: the group shares that many real characters
+                    const u64 avail = a.n - start;
+                    const u64 w = wtext[j];
+                    u32 kcg = kc0;
+                    if (a.L) { const u32 rem = a.L - hsum[j]; kcg = rem < kcg ? rem : kcg; }   // hsum < L while a record is active
+                    const u32 sig = kcg * ub;
+                    const u32 w0 = (u32)w, w1 = (u32)(w >> 32);
+                    const u32 c0 = s_map[w0 & 255u], c1 = s_map[(w0 >> 8) & 255u], c2 = s_map[(w0 >> 16) & 255u], c3 = s_map[w0 >> 24];
+                    u64 f;
+                    if (ub <= 8) {   // uniform
+                        const u32 c4 = s_map[w1 & 255u], c5 = s_map[(w1 >> 8) & 255u], c6 = s_map[(w1 >> 16) & 255u], c7 = s_map[w1 >> 24];
+                        const u32 hi4 = (((((c0 << ub) | c1) << ub) | c2) << ub) | c3;
+                        const u32 lo4 = (((((c4 << ub) | c5) << ub) | c6) << ub) | c7;
+                        u64 all = ((u64)hi4 << (4 * ub)) | lo4;          // character 0 on top, 8 * b <= 64 bits
+                        if (avail < 8) all = avail ? (all & (~0ull << (ub * (8 - (u32)avail)))) : 0ull;
+                        f = (8 * ub >= (u32)FIN_FIELD) ? (all >> (8 * ub - (u32)FIN_FIELD)) : (all << ((u32)FIN_FIELD - 8 * ub));
+                    } else {         // b == 9: four characters
+                        u64 hi = ((((((u64)c0 << ub) | c1) << ub) | c2) << ub) | c3;
+                        if (avail < 4) hi = avail ? (hi & (~0ull << (ub * (4 - (u32)avail)))) : 0ull;
+                        f = hi << ((u32)FIN_FIELD - 4 * ub);
+                    }
+                    f &= ~0ull << ((u32)FIN_FIELD - sig);               // characters beyond kc (and L) do not count
+                    key[j] = (f << (2 * FIN_POS_BITS)) | ((u64)q << FIN_POS_BITS);
+                    s_key[q] = key[j];
+                }
+            }
+        }
+        if (a.debug) { const long long t = clock64(); t_fetch += t - t_mark; t_mark = t; }
+        sync_lds();   // keys in place; s_big / s_nbig complete (LDS atomics above)
+        const u32 nbig = (u32)__builtin_amdgcn_readfirstlane((int)s_nbig);
+        if (nbig) { ++dbg_bigrounds; }
+
+        // 2a. small groups: a record's place inside its group = the members with a smaller key (keys are distinct: they
+        //     carry the compact index, which also keeps ties in text order)
+        u32 dst[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            dst[j] = 0;
+            if (j < R) {
+                const u32 q = woff + j * WAVE;
+                if (q < A) {
+                    const u32 g = s_lgid[q];
+                    const u32 q0 = s_gqp[g] & 0xFFFFu, q1 = s_gqp[g + 1] & 0xFFFFu;
+                    if (q1 - q0 <= cm) {
+                        u32 rank = 0;
+                        const u64 kj = key[j];
+                        for (u32 m = q0; m < q1; m += 4) {
+                            const u64 k0 = s_key[m], k1 = s_key[(m + 1) & PM], k2 = s_key[(m + 2) & PM], k3 = s_key[(m + 3) & PM];
+                            rank += (k0 < kj ? 1u : 0u) + ((m + 1 < q1 && k1 < kj) ? 1u : 0u) + ((m + 2 < q1 && k2 < kj) ? 1u : 0u) +
+                                    ((m + 3 < q1 && k3 < kj) ? 1u : 0u);
+                        }
+                        dst[j] = q0 + rank;
+                    } else dst[j] = ~0u;   // its place comes from the wave that splits the group
+                }
+            }
+        }
+        // 2b. large groups, one wave each (no workgroup barrier inside); four rows of 64 members in flight per step
+        for (u32 bi = (u32)wave; bi < nbig; bi += WAVES) {
+            const u32 g = s_big[bi];
+            const u32 q0 = s_gqp[g] & 0xFFFFu, q1 = s_gqp[g + 1] & 0xFFFFu, m = q1 - q0;
+            dbg_bigrec += m;
+            u32 kcg = kc0;
+            if (a.L) { const u32 rem = a.L - (a.h0 + (u32)s_gh[g]); kcg = rem < kcg ? rem : kcg; }
+            const u32 sigmax = kcg * ub;
+            const u64 f0 = s_key[q0] >> (2 * FIN_POS_BITS);
+            u64 x = 0;
+            for (u32 r0 = 0; r0 < m; r0 += 4 * WAVE) {
+                u64 kk[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const u32 r = r0 + u * WAVE + lane; kk[u] = s_key[q0 + (r < m ? r : 0u)]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x |= (kk[u] >> (2 * FIN_POS_BITS)) ^ f0;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x |= __shfl_xor(x, o);
+            const u32 lcp = x ? (u32)__clzll((long long)x) - (u32)(64 - FIN_FIELD) : (u32)FIN_FIELD;
+            u32 sig;
+            if (lcp >= sigmax) {
+                // every member has the same kc characters: nothing to order, the group moves on as it is
+                sig = sigmax;
+                for (u32 r = lane; r < m; r += 64) {
+                    u32* lo = reinterpret_cast<u32*>(&s_key[q0 + r]);
+                    *lo = (*lo & ~PM) | (q0 + r);
+                }
+            } else {
+                const u32 W = (sigmax - lcp) < (u32)FIN_SPLIT ? (sigmax - lcp) : (u32)FIN_SPLIT;
+                const u32 shift = (u32)(2 * FIN_POS_BITS) + (u32)FIN_FIELD - lcp - W;
+                const u32 mask = (1u << W) - 1u;
+                u32* wh32 = reinterpret_cast<u32*>(wh);   // two 16-bit digit counters per word (a group has at most CAP members)
+                for (u32 i2 = lane; i2 < (1u << FIN_SPLIT) / 2; i2 += 64) wh32[i2] = 0;
+                __builtin_amdgcn_wave_barrier();
+                for (u32 r0 = 0; r0 < m; r0 += 4 * WAVE) {
+                    u64 kk[4]; u32 dd[4], below[4], total[4], lead[4], prior[4];
+                    bool valid[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const u32 r = r0 + u * WAVE + lane;
+                        valid[u] = r < m;
+                        kk[u] = s_key[q0 + (valid[u] ? r : 0u)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        dd[u] = valid[u] ? ((u32)(kk[u] >> shift) & mask) : 0u;
+                        u32 plo = ~0u, phi = ~0u;
+#pragma unroll
+                        for (int bb = 0; bb < FIN_SPLIT; ++bb) {
+                            u32 e = (u32)__builtin_amdgcn_sbfe((int)dd[u], bb, 1);
+                            asm("" : "+v"(e));
+                            const u64 mm = __ballot(e != 0);
+                            plo &= ~((u32)mm ^ e);
+                            phi &= ~((u32)(mm >> 32) ^ e);
+                        }
+                        const u64 vm = __ballot(valid[u]);
+                        plo &= (u32)vm; phi &= (u32)(vm >> 32);
+                        below[u] = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+                        total[u] = (u32)__popc(plo) + (u32)__popc(phi);
+                        lead[u] = plo ? (u32)__builtin_ctz(plo) : 32u + (u32)__builtin_ctz(phi | 0x80000000u);   // a valid lane is its own peer
+                    }
+                    // the first lane of every digit adds its row's count and learns how many members of earlier rows carry the digit
+                    // (the returning atomics of one wave are served in program order: row after row, stable)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        prior[u] = 0;
+                        if (valid[u] && below[u] == 0)
+                            prior[u] = (atomicAdd(&wh32[dd[u] >> 1], total[u] << (16u * (dd[u] & 1u))) >> (16u * (dd[u] & 1u))) & 0xFFFFu;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const u32 pr = (u32)__shfl((int)prior[u], (int)lead[u]);
+                        if (valid[u]) {
+                            u32* lo32 = reinterpret_cast<u32*>(&s_key[q0 + r0 + u * WAVE + lane]);
+                            *lo32 = ((u32)kk[u] & ~PM) | (pr + below[u]);   // rank among the members with this digit
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                {   // exclusive prefix of the digit counts
+                    const u32 bins = 1u << W;
+                    const u32 per = bins >= 64u ? bins / 64u : 1u;
+                    constexpr u32 PER_MAX = (1 << FIN_SPLIT) / 64 > 0 ? (1 << FIN_SPLIT) / 64 : 1;
+                    u32 v[PER_MAX];
+                    u32 sum = 0;
+#pragma unroll
+                    for (u32 e = 0; e < PER_MAX; ++e) {
+                        const u32 bin = (u32)lane * per + e;
+                        v[e] = (e < per && bin < bins) ? (u32)wh[bin] : 0u;
+                        sum += v[e];
+                    }
+                    u32 incl = sum;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const u32 t = __shfl_up(incl, o);
+                        if (lane >= o) incl += t;
+                    }
+                    u32 run = incl - sum;
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (u32 e = 0; e < PER_MAX; ++e) {
+                        const u32 bin = (u32)lane * per + e;
+                        if (e < per && bin < bins) { wh[bin] = (u16)run; run += v[e]; }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (u32 r0 = 0; r0 < m; r0 += 4 * WAVE) {
+                    u64 kk[4]; u32 base[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const u32 r = r0 + u * WAVE + lane; kk[u] = s_key[q0 + (r < m ? r : 0u)]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) base[u] = wh[(u32)(kk[u] >> shift) & mask];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const u32 r = r0 + u * WAVE + lane;
+                        if (r < m) {
+                            u32* lo32 = reinterpret_cast<u32*>(&s_key[q0 + r]);
+                            *lo32 = ((u32)kk[u] & ~PM) | (q0 + base[u] + ((u32)kk[u] & PM));
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                sig = lcp + W;
+            }
+            if (lane == 0) s_gsig[g] = (u8)sig;
+        }
+        if (a.debug) { const long long t = clock64(); t_sort += t - t_mark; t_mark = t; }
+        __syncthreads();   // every place is known; the keys of the small groups have been read
+        if (nbig) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                if (j < R) {
+                    const u32 q = woff + j * WAVE;
+                    if (q < A && dst[j] == ~0u) { const u64 k = s_key[q]; dst[j] = (u32)k & PM; key[j] = k; }
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if (j < R) { const u32 q = woff + j * WAVE; if (q < A) s_key[dst[j]] = key[j]; }
+        }
+        __syncthreads();
+        if (a.debug) { const long long t = clock64(); t_perm += t - t_mark; t_mark = t; }
+
+        // 3. new groups, finals (straight to their SA slots), compaction of what is still tied
+        u32 r_idx[ITEMS], r_ph[ITEMS];   // r_ph: position in the tile | new depth << 16
+        u64 m_act[ITEMS], m_head[ITEMS];
+        u32 finmask = 0, headmask = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            m_act[j] = 0; m_head[j] = 0; r_idx[j] = 0; r_ph[j] = 0;
+            if (j < R) {
+                const u32 q = woff + j * WAVE;
+                const bool valid = q < A;
+                bool head = false, fin = false;
+                if (valid) {
+                    const u32 g = s_lgid[q];                        // q's group is the one it had before: sorting stays inside groups
+                    const u32 gqp = s_gqp[g];
+                    const u32 q0 = gqp & 0xFFFFu, q1 = s_gqp[g + 1] & 0xFFFFu;
+                    const u32 gh = s_gh[g];
+                    u32 sig = s_gsig[g];
+                    if (sig == 0) {
+                        u32 kcg = kc0;
+                        if (a.L) { const u32 rem = a.L - (a.h0 + gh); kcg = rem < kcg ? rem : kcg; }
+                        sig = kcg * ub;
+                    }
+                    const u32 cs = (u32)(2 * FIN_POS_BITS) + (u32)FIN_FIELD - sig;   // sig >= 1
+                    const u64 kq = s_key[q];
+                    const u64 k = kq >> cs;
+                    const u64 kp = s_key[(q - 1) & PM] >> cs, kn = s_key[(q + 1) & PM] >> cs;
+                    head = (q == q0) || (k != kp);
+                    const bool tail = (q + 1 == q1) || (kn != k);
+                    const u32 newh = gh + ((sig * inv_b) >> 16);
+                    fin = (head && tail) || (a.L && a.h0 + newh >= a.L);
+                    r_idx[j] = s_idx[(u32)(kq >> FIN_POS_BITS) & PM];   // the record that now stands at q
+                    r_ph[j] = ((gqp >> 16) + (q - q0)) | (newh << 16);
+                }
+                if (fin) { finmask |= 1u << j; if (head) headmask |= 1u << j; }
+                const bool act = valid && !fin;
+                m_act[j] = __ballot(act);
+                m_head[j] = __ballot(act && head);
+                if (lane == 0) { s_rowa[wave * ITEMS + j] = (u32)__popcll(m_act[j]); s_rowh[wave * ITEMS + j] = (u32)__popcll(m_head[j]); }
+            }
+        }
+        // finals: the slot loads of a lane are requested here, the stores follow the compaction below
+        u32 slotv[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            slotv[j] = 0;
+            if (j < R && ((finmask >> j) & 1u)) slotv[j] = a.apos[begin + (r_ph[j] & 0xFFFFu)];
+        }
+        __syncthreads();   // every read of s_key / s_idx / s_lgid / s_gqp / s_gh / s_gsig of this round is done
+        u32 ia = s_rowa[lane], ih = s_rowh[lane];   // every wave scans the 64 row counts
+        const u32 ca = ia, ch = ih;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 ta = __shfl_up(ia, o), th = __shfl_up(ih, o);
+            if (lane >= o) { ia += ta; ih += th; }
+        }
+        const u32 tot_a = (u32)__builtin_amdgcn_readlane((int)ia, 63), tot_h = (u32)__builtin_amdgcn_readlane((int)ih, 63);
+        const u32 ea = ia - ca, eh = ih - ch;
+        const u64 lt_mask = lanemask_lt();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if (j < R) {
+                const u32 row = (u32)wave * ITEMS + j;
+                const u32 base_a = __shfl(ea, (int)row), base_h = __shfl(eh, (int)row);
+                if ((m_act[j] >> lane) & 1ull) {
+                    const u32 na = base_a + (u32)__popcll(m_act[j] & lt_mask);
+                    const u32 ng = base_h + (u32)__popcll(m_head[j] & (lt_mask | (1ull << lane))) - 1u;
+                    s_idx[na] = r_idx[j];
+                    s_lgid[na] = (u16)ng;
+                    if ((m_head[j] >> lane) & 1ull) {
+                        s_gqp[ng] = na | ((r_ph[j] & 0xFFFFu) << 16);
+                        s_gh[ng] = (u8)(r_ph[j] >> 16);
+                        s_gsig[ng] = 0;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if (j < R && ((finmask >> j) & 1u)) {
+                a.sa[slotv[j]] = r_idx[j];
+                if ((headmask >> j) & 1u) a.gflags[slotv[j]] = 1;
+                a.done[begin + (r_ph[j] & 0xFFFFu)] = 1;
+                ++resolved;
+            }
+        }
+        stall = (tot_a < A || tot_h > G) ? 0u : stall + 1u;
+        if (tid == 0) { s_A = tot_a; s_G = tot_h; s_gqp[tot_h] = tot_a; s_nbig = 0; }
+        __syncthreads();
+        ++rounds;
+        if (a.debug) { const long long t = clock64(); t_regroup += t - t_mark; t_mark = t; }
+    }
+    sync_lds();   // s_fail / s_anyfail complete; the finals of every lane have reached memory (workgroup scope)
+    if (__builtin_amdgcn_readfirstlane((int)s_anyfail)) {
+        // a group the tile gave up on goes back to the global path EXACTLY as it was: the slots of its members that had
+        // already been written get their suffix of the list back, the head marks inside it are taken back
+        for (u32 p = tid; p < cnt; p += FIN_BLOCK) {
+            const u32 gp = a.gid[begin + p];
+            const u32 og = gp - gid0;
+            if (((s_fail[og >> 5] >> (og & 31)) & 1u) && a.done[begin + p]) {
+                const u32 slot = a.apos[begin + p];
+                a.sa[slot] = a.aidx[begin + p];
+                a.gflags[slot] = (p == 0 || a.gid[begin + p - 1] != gp) ? (u8)1 : (u8)2;   // bit0 = head of a group
+                a.done[begin + p] = 0;
+                --resolved;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) resolved += __shfl_down(resolved, o);
+    if (lane == 0 && resolved) atomicAdd(&a.totals[1], (unsigned long long)(long long)(int)resolved);
+    if (tid == 0) {
+        atomicAdd(&a.totals[0], (unsigned long long)cnt);
+        if (a.debug) {
+            atomicAdd(&a.totals[2], (unsigned long long)rounds); atomicAdd(&a.totals[3], (unsigned long long)dbg_bigrounds);
+            atomicAdd(&a.totals[4], (unsigned long long)dbg_bigrec); atomicAdd(&a.totals[5], (unsigned long long)dbg_slots);
+            atomicAdd(&a.totals[6], 1ull); atomicAdd(&a.totals[7], (unsigned long long)dbg_act);
+            atomicAdd(&a.totals[8], (unsigned long long)t_fetch); atomicAdd(&a.totals[9], (unsigned long long)t_sort);
+            atomicAdd(&a.totals[10], (unsigned long long)t_perm); atomicAdd(&a.totals[11], (unsigned long long)t_regroup);
+            atomicAdd(&a.totals[12], (unsigned long long)(clock64() - t_mark));
+        }
+    }
+}
+
 
 }  // namespace sa

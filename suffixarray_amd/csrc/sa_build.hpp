@@ -1158,9 +1158,13 @@ struct Builder {
     bool local_rounds = true;         // SA_HIP_LOCAL_ROUNDS: rounds sorted group-wise in LDS (round_sort.hpp)
     DevBuf gstart, loc_tiles, big_keys, big_vals;
     bool group_finish = true;         // SA_HIP_GROUP_FINISH: groups that fit a tile are refined to the end in LDS (group_finish.hpp)
+    bool fin_prefetch = false;        // SA_HIP_FIN_PREFETCH=1: the finisher's first-round text fetches as a kernel of their own (measured slower: the gather costs what it saves)
+    bool fin_v2 = false;              // SA_HIP_FIN_V2=1: round 4's restructured finisher (group_finish2_kernel); measured 0-2 % SLOWER than the round-2 kernel
+                                      // (profiles/r04_finisher_v2_ab.log), so it is not the default
     bool fin_useful = true;           // per build: cleared when a run resolves less than a quarter of what it looked at
     bool use_pilot = true;            // SA_HIP_PILOT: 0 = initial key length from the byte distribution alone
     DevBuf fin_flag;                  // u8[M]: per list position, final / head marks of the finisher
+    DevBuf fin_w0;                    // u64[M]: per list position, the text bytes of the finisher's first round (fin_prefetch_kernel)
     bool period_finish = true;        // SA_HIP_PERIOD_FINISH: arithmetic groups inside one periodic run are ordered in one step (period_finish.hpp)
     int per_skip = 0, per_fails = 0;  // per build: an attempt that orders less than an eighth of the active set is repeated only after 2, 4, 8 ... rounds
     DevBuf per_gd, per_bad, per_table, per_dec, per_tf, per_carry;
@@ -1263,6 +1267,8 @@ struct Builder {
         if (const char* e = diag_env("SA_HIP_LITE_FLAGS")) lite_flags = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_LOCAL_ROUNDS")) local_rounds = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_GROUP_FINISH")) group_finish = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_FIN_V2")) fin_v2 = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_FIN_PREFETCH")) fin_prefetch = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_PILOT")) use_pilot = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_PERIOD_FINISH")) period_finish = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_SECTOR_SEARCH")) sector_search = atoi(e);
@@ -1299,7 +1305,7 @@ struct Builder {
     void destroy() {
         DevBuf* all[] = {&text, &keys0, &keys1, &vals0, &vals1, &flags, &counts, &small, &isa, &apos0, &apos1, &apos2, &aidx,
                          &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir, &dbg, &done, &pilot,
-                         &gstart, &loc_tiles, &big_keys, &big_vals, &fin_flag, &per_gd, &per_bad, &per_table, &per_dec, &per_tf, &per_carry};
+                         &gstart, &loc_tiles, &big_keys, &big_vals, &fin_flag, &fin_w0, &per_gd, &per_bad, &per_table, &per_dec, &per_tf, &per_carry};
         for (DevBuf* b : all) b->release();
         radix.destroy();
         narrow.destroy();
@@ -1712,7 +1718,18 @@ struct Builder {
         a.count_max = fin_count_max; a.radix_chars = fin_radix_chars; a.debug = debug_rounds ? 1 : 0;
         a.sa = sa; a.gflags = flags.as<u8>(); a.done = done.as<u8>();
         a.res_idx = ridx0.as<u32>(); a.res_fin = fin_flag.as<u8>(); a.totals = ft;
-        hipLaunchKernelGGL(group_finish_kernel, dim3(ntiles), dim3(FIN_BLOCK), 0, stream, a, map);
+        if (fin_v2) {
+            // (ridx0 = the list's ping-pong partner, free here: 4 bytes per record; the fetched words need 8)
+            a.w0 = nullptr;
+            if (fin_prefetch) {
+                if ((rc = fin_w0.ensure((size_t)M * 8 + 64))) return rc;
+                a.w0 = fin_w0.as<u64>();
+                hipLaunchKernelGGL(fin_prefetch_kernel, dim3(ntiles), dim3(256), 0, stream, (const u8*)text.as<u8>(), (const u32*)aidx.as<u32>(),
+                                   (const LocTile*)loc_tiles.as<LocTile>(), (u32)h, fin_w0.as<u64>());
+            }
+            hipLaunchKernelGGL(group_finish2_kernel, dim3(ntiles), dim3(FIN_BLOCK), 0, stream, a, map);
+        }
+        else hipLaunchKernelGGL(group_finish_kernel, dim3(ntiles), dim3(FIN_BLOCK), 0, stream, a, map);
         unsigned long long ft_host[32] = {0};
         SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_FT, ft, 256, hipMemcpyDeviceToHost, stream));
         const u32 tiles = div_up(M, BLD_TILE);
@@ -1729,8 +1746,9 @@ struct Builder {
                     "slots radix %llu counting %llu, active record-rounds %llu\n", (unsigned long long)h, M, G, ntiles, ft_host[6], ft_host[0], ft_host[1],
                     tot[0], tot[1], ft_host[2], ft_host[3], ft_host[4], ft_host[5], ft_host[7]);
         if (debug_rounds && ft_host[6])
-            fprintf(stderr, "[sa_hip]   finisher cycles per tile (thread 0, clock64): fetch+keys %llu, counting sort %llu, radix sort %llu, regroup %llu, write-out %llu\n",
-                    ft_host[8] / ft_host[6], ft_host[9] / ft_host[6], ft_host[10] / ft_host[6], ft_host[11] / ft_host[6], ft_host[12] / ft_host[6]);
+            fprintf(stderr, fin_v2 ? "[sa_hip]   finisher v2 (rounds with a split group %llu; split records seen by wave 0: %llu) cycles per tile (thread 0, clock64): fetch+keys %llu, counting + splits %llu, permutation %llu, regroup + finals %llu, tail %llu\n"
+                                   : "[sa_hip]   finisher (radix rounds %llu, radix slots %llu) cycles per tile (thread 0, clock64): fetch+keys %llu, counting sort %llu, radix sort %llu, regroup %llu, write-out %llu\n",
+                    ft_host[3], ft_host[4], ft_host[8] / ft_host[6], ft_host[9] / ft_host[6], ft_host[10] / ft_host[6], ft_host[11] / ft_host[6], ft_host[12] / ft_host[6]);
         if (debug_rounds && ft_host[6]) {
             fprintf(stderr, "[sa_hip]   records by group size at entry [2^c, 2^(c+1)):");
             for (int c = 1; c < 13; ++c) fprintf(stderr, " %d:%llu", c, ft_host[16 + c]);

@@ -367,16 +367,22 @@ def test_group_finisher_matches_global_rounds(gpu, oracle, monkeypatch):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got, stats = {}, {}
-        for mode in ("1", "0"):
-            monkeypatch.setenv("SA_HIP_GROUP_FINISH", mode)
+        for mode in ("1", "v2", "0"):
+            # "v2": round 4's restructured finisher (group_finish2_kernel: per-group depth, large groups split apart by one
+            # wave each, finals straight to their SA slots, failed groups restored) -- measured no faster, kept for A/B
+            monkeypatch.setenv("SA_HIP_GROUP_FINISH", "0" if mode == "0" else "1")
+            monkeypatch.setenv("SA_HIP_FIN_V2", "1" if mode == "v2" else "0")
             with gpu.DeviceIndex(t.size, 0) as idx:
                 idx.build(t, L)
                 stats[mode] = idx.build_stats()
                 assert idx.verify() == 0, (name, mode, stats[mode])
                 got[mode] = idx.sa_u32().copy()
+        monkeypatch.delenv("SA_HIP_FIN_V2", raising=False)
         for k in env:
             monkeypatch.delenv(k, raising=False)
         assert np.array_equal(got["1"], got["0"]), (name, stats)
+        assert np.array_equal(got["v2"], got["0"]), (name, stats)
+        assert stats["v2"]["finisher_runs"] > 0 or stats["1"]["finisher_runs"] == 0, (name, stats)
         assert stats["0"]["finisher_runs"] == 0
         if name.startswith("words") and L not in (1, 9):   # (L <= the initial key length: nothing to refine)
             assert stats["1"]["finisher_resolved"] > 0 and stats["1"]["active_total"] < stats["0"]["active_total"], (name, stats)

@@ -22,13 +22,11 @@ elif kind == "repeat":
     rng = np.random.default_rng(1)
     t = np.tile(rng.integers(97, 123, 1 << 20, dtype=np.uint8), n // (1 << 20) + 1)[:n].copy()
 elif kind == "names":
-    from csv_ingest import extract_column
     rows = n // 18   # ~18.3 column characters per row
     path = "/tmp/companies_%d.csv" % rows
     _capi.synth_csv(path, rows, 1)
-    col = extract_column(path, "company_name")
+    t = np.array(_capi.csv_extract_column(path, "company_name", copy=False)[1])
     os.remove(path)
-    t = np.frombuffer(col.text, dtype=np.uint8)
 else:
     raise SystemExit("unknown kind " + kind)
 with _capi.DeviceIndex(t.size, 0) as idx:
