@@ -60,11 +60,30 @@ int32_t sa_hip_libsais(const uint8_t* T, int32_t* SA, int32_t n, int32_t fs, int
 int32_t sa_hip_libsais_omp(const uint8_t* T, int32_t* SA, int32_t n, int32_t fs, int32_t* freq, int32_t threads);
 /* replaces libsais64 (libsais64.h:61, libsais64.c:6657) for n <= UINT32_MAX - 1: 32-bit device
  * build + widening (the reference does the same on the CPU for n <= INT32_MAX, libsais64.c:6670-6682).
- * n > 2^32 - 2 is REFUSED (-1): the true 64-bit path of the reference (libsais64.c:6684 -> libsais64_main) has no
- * counterpart here -- one index holds at most 2^32 - 2 bytes of text (outside every BASELINE configuration). */
+ * n > 2^32 - 2 (round 4): the counterpart of the reference's true 64-bit path (libsais64.c:6684 -> libsais64_main) --
+ * 64-bit suffix indices on the device (csrc/big_build.hpp: radix sort of (u64 key, u64 suffix) records + prefix doubling
+ * on what stays tied), 41 bytes of HBM per character: texts up to about 6.5e9 bytes on one 288 GB GPU, SA_HIP_ENOMEM (-2)
+ * beyond.  A functional completion, outside every BASELINE configuration: plain (unpinned) copies, no shared workspace. */
 int64_t sa_hip_libsais64(const uint8_t* T, int64_t* SA, int64_t n, int64_t fs, int64_t* freq);
 /* replaces libsais64_omp (libsais64.h:86, libsais64.c:6783). */
 int64_t sa_hip_libsais64_omp(const uint8_t* T, int64_t* SA, int64_t n, int64_t fs, int64_t* freq, int64_t threads);
+
+/* The 64-bit-index build on device buffers (what sa_hip_libsais64 runs for n > 2^32 - 2; any n >= 0 is accepted, which is how
+ * the tests compare it with the oracle at small sizes): text_dev = n bytes, 16-byte aligned; sa_dev = n int64 entries
+ * (libsais64 layout).  No index handle is involved: the array is the product. */
+typedef struct sa_hip_big_stats {
+    uint32_t sigma, bits_per_symbol, initial_chars;   /* alphabet, bits per character code, characters in the initial key  */
+    uint32_t sort_passes;                             /* 8-bit radix passes over (u64, u64) records, all sorts of the build */
+    uint32_t rounds;                                  /* prefix-doubling rounds                                             */
+    uint32_t pad_;
+    uint64_t tied_after_sort;                         /* suffixes still tied after the initial sort                         */
+    uint64_t tied_total;                              /* sum over the rounds of the tied suffixes they looked at            */
+    float    total_ms;                                /* device time of the build (HIP events)                              */
+} sa_hip_big_stats;
+int sa_hip_libsais64_device(const void* text_dev, int64_t* sa_dev, int64_t n, int device, sa_hip_big_stats* stats /* or NULL */);
+/* sufcheck with 64-bit indices: *violations = slots at which sa_dev is not a permutation of [0, n) in suffix order
+ * (0 <=> it is THE suffix array of text_dev; 8 n bytes of scratch) */
+int sa_hip_sufcheck64_device(const void* text_dev, const int64_t* sa_dev, int64_t n, int device, uint64_t* violations);
 
 /* The four calls above (and sa_hip_construct_truncated_suffix_array) share ONE process-level workspace: a device index
  * whose buffers are allocated on the first call and grow on demand (about 18 bytes of HBM per character of the

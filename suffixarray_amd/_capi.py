@@ -18,6 +18,7 @@ UINT32_MAX = 0xFFFFFFFF
 # every symbol include/sa_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "sa_hip_libsais", "sa_hip_libsais_omp", "sa_hip_libsais64", "sa_hip_libsais64_omp",
+    "sa_hip_libsais64_device", "sa_hip_sufcheck64_device",
     "sa_hip_last_call_breakdown", "sa_hip_release_workspace",
     "sa_hip_construct_truncated_suffix_array", "sa_hip_get_substring_positions",
     "sa_hip_device_count", "sa_hip_index_create", "sa_hip_index_destroy", "sa_hip_index_build",
@@ -77,6 +78,16 @@ class QueryStats(C.Structure):
                 ("pad_", C.c_uint32)]
 
 
+class BigStats(C.Structure):
+    """sa_hip_big_stats: the 64-bit-index build (texts beyond 2^32 - 2 bytes)."""
+    _fields_ = [("sigma", C.c_uint32), ("bits_per_symbol", C.c_uint32), ("initial_chars", C.c_uint32), ("sort_passes", C.c_uint32),
+                ("rounds", C.c_uint32), ("pad_", C.c_uint32), ("tied_after_sort", C.c_uint64), ("tied_total", C.c_uint64),
+                ("total_ms", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad_"}
+
+
 class CallBreakdown(C.Structure):
     _fields_ = [("n", C.c_uint64), ("workspace_reused", C.c_uint32), ("pad_", C.c_uint32), ("total_ms", C.c_double),
                 ("workspace_ms", C.c_double), ("upload_ms", C.c_double), ("build_ms", C.c_double), ("build_device_ms", C.c_double),
@@ -129,6 +140,10 @@ def lib():
     L.sa_hip_libsais64.argtypes = [vp, vp, i64, i64, vp]
     L.sa_hip_libsais64_omp.restype = i64
     L.sa_hip_libsais64_omp.argtypes = [vp, vp, i64, i64, vp, i64]
+    L.sa_hip_libsais64_device.restype = C.c_int
+    L.sa_hip_libsais64_device.argtypes = [vp, vp, i64, C.c_int, C.POINTER(BigStats)]
+    L.sa_hip_sufcheck64_device.restype = C.c_int
+    L.sa_hip_sufcheck64_device.argtypes = [vp, vp, i64, C.c_int, C.POINTER(u64)]
     L.sa_hip_last_call_breakdown.restype = C.c_int
     L.sa_hip_last_call_breakdown.argtypes = [C.POINTER(CallBreakdown)]
     L.sa_hip_release_workspace.restype = None
@@ -599,6 +614,20 @@ def libsais64(text, want_freq=False):
     rc = lib().sa_hip_libsais64(t.ctypes.data, sa.ctypes.data, t.size, 0, freq.ctypes.data if want_freq else None)
     check(int(rc))
     return (sa[:t.size], freq) if want_freq else sa[:t.size]
+
+
+def libsais64_device(text_ptr, sa_ptr, n, device=0):
+    """The 64-bit-index build (csrc/big_build.hpp) on device buffers: text_ptr = n bytes, sa_ptr = n int64 entries.  Returns its stats."""
+    st = BigStats()
+    check(lib().sa_hip_libsais64_device(text_ptr, sa_ptr, n, device, C.byref(st)))
+    return st.as_dict()
+
+
+def sufcheck64_device(text_ptr, sa_ptr, n, device=0):
+    """Slots at which the int64 array on the device is not the suffix array of the text (0 = it is)."""
+    v = C.c_uint64(0)
+    check(lib().sa_hip_sufcheck64_device(text_ptr, sa_ptr, n, device, C.byref(v)))
+    return int(v.value)
 
 
 def construct_truncated_suffix_array(text, max_suffix_length):

@@ -10,6 +10,7 @@
 #include "radix_sort.hpp"
 #include "sa_build.hpp"
 #include "sa_query.hpp"
+#include "big_build.hpp"
 #include "csv_ingest.hpp"
 #include "records.hpp"
 #include "host_io.hpp"
@@ -1572,9 +1573,67 @@ int32_t sa_hip_libsais(const uint8_t* T, int32_t* SA, int32_t n, int32_t fs, int
     return sa_hip_libsais_omp(T, SA, n, fs, freq, 0);
 }
 
+// ---- texts beyond 2^32 - 2 bytes: 64-bit suffix indices (big_build.hpp; libsais64.c:6684 -> libsais64_main) ----------------
+int sa_hip_libsais64_device(const void* text_dev, int64_t* sa_dev, int64_t n, int device, sa_hip_big_stats* stats_out) {
+    if ((!text_dev || !sa_dev) && n) return fail(SA_HIP_EINVAL, "sa_hip_libsais64_device: NULL argument");
+    if (n < 0) return fail(SA_HIP_EINVAL, "sa_hip_libsais64_device: negative length");
+    int rc = set_device(device);
+    if (rc) return rc;
+    big::BigBuilder b;
+    SA_HIP_CHECK(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+    rc = b.build(static_cast<const u8*>(text_dev), (u64)n, reinterpret_cast<u64*>(sa_dev));
+    (void)hipStreamSynchronize(b.stream);
+    if (stats_out) {
+        stats_out->sigma = b.stats.sigma; stats_out->bits_per_symbol = b.stats.bits_per_symbol; stats_out->initial_chars = b.stats.initial_chars;
+        stats_out->sort_passes = b.stats.sort_passes; stats_out->rounds = b.stats.rounds; stats_out->pad_ = 0;
+        stats_out->tied_after_sort = b.stats.tied_after_sort; stats_out->tied_total = b.stats.tied_total; stats_out->total_ms = b.stats.total_ms;
+    }
+    b.destroy();
+    (void)hipStreamDestroy(b.stream);
+    return rc;
+}
+
+int sa_hip_sufcheck64_device(const void* text_dev, const int64_t* sa_dev, int64_t n, int device, uint64_t* violations) {
+    if (!violations || ((!text_dev || !sa_dev) && n) || n < 0) return fail(SA_HIP_EINVAL, "sa_hip_sufcheck64_device: invalid arguments");
+    int rc = set_device(device);
+    if (rc) return rc;
+    big::BigBuilder b;
+    SA_HIP_CHECK(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+    u64 v = 0;
+    rc = b.verify(static_cast<const u8*>(text_dev), reinterpret_cast<const u64*>(sa_dev), (u64)n, &v);
+    *violations = v;
+    b.destroy();
+    (void)hipStreamDestroy(b.stream);
+    return rc;
+}
+
+namespace {
+// host text in, host suffix array out, through plain device buffers (a call of this size is dominated by its 8 n bytes over PCIe)
+int big_oneshot(const uint8_t* T, uint64_t n, int64_t* SA, int64_t* freq) {
+    int rc = set_device(0);
+    if (rc) return rc;
+    DevBuf text, sa;
+    if ((rc = text.ensure(n + 64)) || (rc = sa.ensure(n * 8 + 64))) { text.release(); sa.release(); return rc; }
+    auto body = [&]() -> int {
+        SA_HIP_CHECK(hipMemcpy(text.p, T, n, hipMemcpyHostToDevice));
+        int r = sa_hip_libsais64_device(text.p, sa.as<int64_t>(), (int64_t)n, 0, nullptr);
+        if (r) return r;
+        SA_HIP_CHECK(hipMemcpy(SA, sa.p, n * 8, hipMemcpyDeviceToHost));
+        return 0;
+    };
+    rc = body();
+    text.release(); sa.release();
+    if (rc == 0 && freq) {   // (libsais.h:84: the byte histogram, when asked for)
+        for (int c = 0; c < 256; ++c) freq[c] = 0;
+        for (uint64_t i = 0; i < n; ++i) ++freq[T[i]];
+    }
+    return rc;
+}
+}  // namespace
+
 int64_t sa_hip_libsais64_omp(const uint8_t* T, int64_t* SA, int64_t n, int64_t fs, int64_t* freq, int64_t threads) {
     if (T == nullptr || SA == nullptr || n < 0 || fs < 0 || threads < 0) return fail(SA_HIP_EINVAL, "sa_hip_libsais64: invalid arguments");
-    if ((uint64_t)n > 0xFFFFFFFEull) return fail(SA_HIP_EINVAL, "sa_hip_libsais64: n exceeds 2^32 - 2 (single-GPU 32-bit pipeline)");
+    if ((uint64_t)n > 0xFFFFFFFEull) return big_oneshot(T, (uint64_t)n, SA, freq);   // 64-bit suffix indices (big_build.hpp)
     return oneshot_build<int64_t, int64_t>(T, (uint64_t)n, 0, SA, freq);
 }
 
