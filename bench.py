@@ -333,6 +333,7 @@ def main():
     ap.add_argument("--cpu-one-thread-chars", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-beyond-u32", action="store_true", help="skip secondary.beyond_u32_4p4e9 (a 4.4e9-character text: 64-bit suffix indices, csrc/big_build.hpp)")
     ap.add_argument("--no-words-1e9", action="store_true", help="skip secondary.d2_words_1e9 (D2 words at N = 1e9, 64-bit build + the reference's libsais64_omp)")
     ap.add_argument("--offsets-api", action="store_true", help="query through sa_hip_query_batch_device (offsets array) instead of the fixed-length entry")
     ap.add_argument("--separate-widen", action="store_true", help="int64 output by a widening pass after the build (A/B against the fused form)")
@@ -542,7 +543,42 @@ def run_single(args, torch, _capi, synth, dev, device):
             line["secondary"]["d2_words_1e9"] = d2_words_1e9(_capi, synth, torch, dev, device, with_cpu=not args.no_cpu_baseline)
             gate["d2_words_1e9_ok"] = line["secondary"]["d2_words_1e9"]["ok"]
             gate["ok"] = bool(gate["ok"] and gate["d2_words_1e9_ok"])
+        if N >= 1_000_000_000 and not args.no_beyond_u32:
+            _capi.release_workspace()
+            torch.cuda.empty_cache()
+            big = beyond_u32(_capi, synth, torch, dev, device)
+            if big is not None:
+                line["secondary"]["beyond_u32_4p4e9"] = big
+                gate["beyond_u32_ok"] = big["ok"]
+                gate["ok"] = bool(gate["ok"] and big["ok"])
     return line
+
+
+def beyond_u32(_capi, synth, torch, dev, device, n=4_400_000_000):
+    """A single text of more than 2^32 - 2 bytes (round 4: csrc/big_build.hpp, what sa_hip_libsais64 runs there -- the counterpart
+    of libsais64.c:6684 -> libsais64_main): D1 at n = 4.4e9 built with 64-bit suffix indices on device buffers, checked by the
+    64-bit sufcheck on the device.  None when the GPU has less than 46 bytes of free memory per character."""
+    free, _ = torch.cuda.mem_get_info(device)
+    if free < 46 * n:
+        return None
+    t0 = time.perf_counter()
+    text = synth.d1_uniform27(n)
+    gen_s = time.perf_counter() - t0
+    text_t = torch.from_numpy(text).to(dev)
+    sa_t = torch.empty(n, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ms, st = [], None
+    for _ in range(2):
+        st = _capi.libsais64_device(text_t.data_ptr(), sa_t.data_ptr(), n, device)
+        ms.append(st["total_ms"])
+    bad = _capi.sufcheck64_device(text_t.data_ptr(), sa_t.data_ptr(), n, device)
+    beyond = int((sa_t > 0xFFFFFFFF).sum().item())
+    del sa_t, text_t
+    torch.cuda.empty_cache()
+    return {"n_chars": n, "text": "D1 uniform27", "text_gen_s": gen_s, "build_ms": min(ms), "build_ms_first": ms[0], "chars_per_s": n / (min(ms) / 1e3),
+            "sufcheck64_violations": bad, "entries_beyond_2_32": beyond, "output": "int64[N] libsais64 layout, device resident (64-bit suffix indices throughout)",
+            **{k: st[k] for k in ("sigma", "bits_per_symbol", "initial_chars", "sort_passes", "rounds", "tied_after_sort")},
+            "ok": bool(bad == 0 and beyond == n - (1 << 32))}
 
 
 def query_populations(idx, synth, torch, dev, text, Q, m):

