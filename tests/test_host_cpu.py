@@ -37,15 +37,17 @@ def test_stats_structs_match_the_header(capi, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sa_hip.h"\n'
-                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(sa_hip_build_stats), offsetof(sa_hip_build_stats, radix_ms),'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sa_hip_build_stats), offsetof(sa_hip_build_stats, radix_ms),'
                    ' offsetof(sa_hip_build_stats, pass_ms), offsetof(sa_hip_build_stats, pass_launches), sizeof(sa_hip_query_stats),'
-                   ' sizeof(sa_hip_csv_column)); return 0; }\n')
+                   ' sizeof(sa_hip_csv_column), sizeof(sa_hip_big_stats), offsetof(sa_hip_big_stats, tied_after_sort),'
+                   ' offsetof(sa_hip_big_stats, total_ms)); return 0; }\n')
     exe = tmp_path / "sizes"
     subprocess.run(["gcc", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     B = capi.BuildStats
+    G = capi.BigStats
     assert got == [C.sizeof(B), B.radix_ms.offset, B.pass_ms.offset, B.pass_launches.offset, C.sizeof(capi.QueryStats),
-                   C.sizeof(capi.CsvColumn)], got
+                   C.sizeof(capi.CsvColumn), C.sizeof(G), G.tied_after_sort.offset, G.total_ms.offset], got
 
 
 def test_no_gpu_means_loud_failure(capi):
@@ -56,6 +58,12 @@ def test_no_gpu_means_loud_failure(capi):
         capi.DeviceIndex(1024, 0)
     with pytest.raises(capi.SaHipError):
         capi.libsais(b"banana")
+    import numpy as np
+    buf = np.zeros(64, np.uint8)
+    with pytest.raises(capi.SaHipError):   # the 64-bit-index build and its sufcheck (round 4) refuse as loudly
+        capi.libsais64_device(buf.ctypes.data, buf.ctypes.data, 4)
+    with pytest.raises(capi.SaHipError):
+        capi.sufcheck64_device(buf.ctypes.data, buf.ctypes.data, 4)
 
 
 def test_config1_readme_on_the_opt_in_host_path(capi, oracle, monkeypatch, tmp_path):
