@@ -251,6 +251,15 @@ int sa_hip_index_get_sa_range(sa_hip_index* idx, uint64_t first, uint64_t count,
 int sa_hip_index_query_hits(sa_hip_index* idx, const uint8_t* pattern, uint64_t len, uint32_t max_hits,
                             sa_hip_pair_u32* range, uint32_t* hits, uint32_t* nhits);
 
+/* Second-level keys (round 4; csrc/sa_query.hpp): for the SA slots that share their key (first k0 characters) with a neighbour,
+ * the next floor(64 / b) characters, packed like the key -- 8 n bytes, one gather over those slots.  A pattern longer than the
+ * key then finds its bounds inside a key group by a binary search over 8-byte keys instead of text comparisons (two dependent
+ * random reads per step).  Wide-key indexes only (word / name / DNA text; near-random text has no such groups).
+ *   mode 1 (the default of every handle): the first batch of >= 32768 patterns builds them on its way;
+ *   mode 2: build them now;   mode 0: drop them and never build them (the text search stays).
+ * Returns 1 when the index has them afterwards, 0 when not (narrow keys, no memory, mode 0), < 0 on errors.  The results of
+ * every query are the same with or without; a rebuild / load / replica commit drops them. */
+int sa_hip_index_deep_keys(sa_hip_index* idx, int mode);
 int sa_hip_index_sync(sa_hip_index* idx);
 
 /* On-device check that the index's SA is the suffix array of its text (truncated indexes: that

@@ -18,7 +18,7 @@ UINT32_MAX = 0xFFFFFFFF
 # every symbol include/sa_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "sa_hip_libsais", "sa_hip_libsais_omp", "sa_hip_libsais64", "sa_hip_libsais64_omp",
-    "sa_hip_libsais64_device", "sa_hip_sufcheck64_device",
+    "sa_hip_libsais64_device", "sa_hip_sufcheck64_device", "sa_hip_index_deep_keys",
     "sa_hip_last_call_breakdown", "sa_hip_release_workspace",
     "sa_hip_construct_truncated_suffix_array", "sa_hip_get_substring_positions",
     "sa_hip_device_count", "sa_hip_index_create", "sa_hip_index_destroy", "sa_hip_index_build",
@@ -144,6 +144,8 @@ def lib():
     L.sa_hip_libsais64_device.argtypes = [vp, vp, i64, C.c_int, C.POINTER(BigStats)]
     L.sa_hip_sufcheck64_device.restype = C.c_int
     L.sa_hip_sufcheck64_device.argtypes = [vp, vp, i64, C.c_int, C.POINTER(u64)]
+    L.sa_hip_index_deep_keys.restype = C.c_int
+    L.sa_hip_index_deep_keys.argtypes = [vp, C.c_int]
     L.sa_hip_last_call_breakdown.restype = C.c_int
     L.sa_hip_last_call_breakdown.argtypes = [C.POINTER(CallBreakdown)]
     L.sa_hip_release_workspace.restype = None
@@ -465,6 +467,17 @@ class DeviceIndex:
 
     def sync(self):
         check(self._lib.sa_hip_index_sync(self._h))
+
+    def deep_keys(self, mode=2):
+        """Second-level keys for patterns longer than the key (sa_hip_index_deep_keys): 2 = build now, 1 = large batches build
+        them (default of a handle), 0 = drop and never build.  True when the index has them afterwards."""
+        rc = self._lib.sa_hip_index_deep_keys(self._h, mode)
+        if rc < 0:
+            check(rc)
+        return rc == 1
+
+    def prepare_deep_keys(self):
+        return self.deep_keys(2)
 
     def verify(self):
         """Number of violations of the suffix-array property found on the device (0 = verified)."""

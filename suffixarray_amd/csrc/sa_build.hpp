@@ -1190,6 +1190,13 @@ struct Builder {
     bool debug_rounds = false;
     // query acceleration (sa_query.hpp): sorted packed keys K + bucket directory
     const u64* qkeys = nullptr;   // points into keys0/keys1 (build) or keys0 (load)
+    // Second-level keys (round 4, sa_query.hpp: k2_build_kernel): for every SA slot whose key equals a neighbour's, the q_k2n
+    // characters that FOLLOW the key's q_k0, packed like the key.  Built on demand (the first large batch of a wide-key index,
+    // or sa_hip_index_deep_keys), 8 n bytes; k2_ready falls with every change of qkeys.
+    DevBuf qkeys2;
+    DevBuf qskeys;   // every 64th key of qkeys (sa_query.hpp: SKEY_STRIDE), built with qkeys2
+    bool k2_ready = false;
+    int q_k2n = 0;
     // ... or, after a narrow-record sort (narrow_k): u32 narrow keys + the 257 bucket bounds of the top digit;
     // key of slot j = (bucket(j) << 56) | (qkeys32[j] << q_lo_shift).  Exactly one of qkeys / qkeys32 is set.
     const u32* qkeys32 = nullptr;
@@ -1308,7 +1315,7 @@ struct Builder {
     void destroy() {
         DevBuf* all[] = {&text, &keys0, &keys1, &vals0, &vals1, &flags, &counts, &small, &isa, &apos0, &apos1, &apos2, &aidx,
                          &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir, &dbg, &done, &pilot,
-                         &gstart, &loc_tiles, &big_keys, &big_vals, &fin_flag, &fin_w0, &per_gd, &per_bad, &per_table, &per_dec, &per_tf, &per_carry};
+                         &gstart, &loc_tiles, &big_keys, &big_vals, &fin_flag, &fin_w0, &qkeys2, &qskeys, &per_gd, &per_bad, &per_table, &per_dec, &per_tf, &per_carry};
         for (DevBuf* b : all) b->release();
         radix.destroy();
         narrow.destroy();
@@ -1561,7 +1568,7 @@ struct Builder {
 
     // Directory by binary search (adopted indexes; a build gets it from its first flags pass)
     int build_directory() {
-        if ((!qkeys && !qkeys32) || n < 2) { qkeys = nullptr; qkeys32 = nullptr; return 0; }
+        if ((!qkeys && !qkeys32) || n < 2) { qkeys = nullptr; qkeys32 = nullptr; k2_ready = false; return 0; }
         if (qkeys32 && !dir_ready) return fail(SA_HIP_EINTERNAL, "narrow keys without a fused directory");
         if (dir_ready) {
             // (also worth it beyond the cache's 256 MiB: at 26 bits the first batch after a build takes 0.125 ms with
@@ -1593,6 +1600,7 @@ struct Builder {
         qkeys = nullptr;
         qkeys32 = nullptr;
         dir_ready = false;
+        k2_ready = false;
         if (n < 2) return 0;
         const int k0 = choose_initial_chars(b, L);
         int rc = keys0.ensure((size_t)n * 8 + 64);
@@ -1860,6 +1868,7 @@ struct Builder {
         qkeys = nullptr;
         qkeys32 = nullptr;
         dir_ready = false;
+        k2_ready = false;
         stats.widen_fused = 0;
         if (n == 0) return finish_stats();
         if (n == 1) {

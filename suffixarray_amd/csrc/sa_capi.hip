@@ -51,6 +51,7 @@ struct sa_hip_index {
     DevBuf r_rows, r_counts;       // results of the rows kernel (batched form)
     std::unique_ptr<HostIndex> host;   // set: the opt-in no-GPU path of config 1 (host_index.hpp); nothing below touches HIP then
     bool receiving = false;        // sa_hip_index_replica_reserve .. _commit: the buffers are being filled by the caller
+    bool k2_auto = true;           // sa_hip_index_deep_keys: large batches build the second-level keys on their way
     sa_hip_replica_layout pending{};
 };
 
@@ -94,8 +95,32 @@ int resolve_query_events(sa_hip_index* idx, int count) {
     return 0;
 }
 
+// second-level keys of a wide-key index (sa_query.hpp: k2_build_kernel), built once per index state; the caller holds idx->mu
+// and has set the device.  Without memory for them (8 n bytes) the text search stays: not an error.
+constexpr u64 K2_AUTO_BATCH = 32768;   // a batch of at least this many patterns builds them on its way (one gather over the tied slots)
+int ensure_k2(sa_hip_index* idx) {
+    Builder& b = idx->b;
+    if (b.k2_ready || !b.qkeys || b.n < 2 || !idx->has_index) return 0;
+    static const bool off = [] { const char* e = diag_env("SA_HIP_K2"); return e && atoi(e) == 0; }();
+    if (off) return 0;
+    int k2n = 64 / (b.q_b > 0 ? b.q_b : 1);
+    if (k2n > 16) k2n = 16;
+    if (b.qkeys2.ensure((size_t)b.n * 8 + 64)) return 0;
+    if (b.qskeys.ensure(((size_t)b.n / SKEY_STRIDE + 2) * 8 + 64)) return 0;
+    hipLaunchKernelGGL(skeys_kernel, dim3(stream_grid(b.n / SKEY_STRIDE + 1, 256)), dim3(256), 0, idx->stream, b.qkeys, b.n, b.qskeys.as<u64>());
+    hipLaunchKernelGGL(k2_build_kernel, dim3(stream_grid(b.n, 256)), dim3(256), 0, idx->stream, b.qkeys, (const u32*)b.sa, (const u8*)b.text.as<u8>(), b.n,
+                       b.qmap, b.q_b, b.q_k0, k2n, b.max_suffix_length, b.qkeys2.as<u64>());
+    SA_HIP_CHECK(hipGetLastError());
+    b.q_k2n = k2n;
+    b.k2_ready = true;
+    return 0;
+}
+
 QueryArgs query_args(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q, sa_hip_pair_u32* out_dev, u64 fixed_len) {
     QueryArgs a;
+    a.keys2 = idx->b.k2_ready ? idx->b.qkeys2.as<u64>() : nullptr;
+    a.skeys = idx->b.k2_ready ? idx->b.qskeys.as<u64>() : nullptr;
+    a.k2n = idx->b.q_k2n;
     a.fixed_len = fixed_len;
     a.text = idx->b.text.as<u8>();
     a.sa = idx->b.sa;
@@ -117,6 +142,7 @@ QueryArgs query_args(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u
 int launch_query(sa_hip_index* idx, const u8* pat_dev, const u64* off_dev, u64 Q, sa_hip_pair_u32* out_dev, u64 fixed_len = 0) {
     if (idx->q_pending == sa_hip_index::QRING) { int rc = resolve_query_events(idx, 1); if (rc) return rc; }
     hipEvent_t* ev = idx->q_ev[idx->q_head];
+    if (Q >= K2_AUTO_BATCH && idx->k2_auto) { int rc = ensure_k2(idx); if (rc) return rc; }
     const QueryArgs a = query_args(idx, pat_dev, off_dev, Q, out_dev, fixed_len);
     SA_HIP_CHECK(hipEventRecord(ev[0], idx->stream));
     if (Q) {
@@ -441,7 +467,7 @@ int sa_hip_index_replica_reserve(sa_hip_index* idx, const sa_hip_replica_layout*
     SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
     b.n = l->n;
     b.sa = b.sa_own.as<u32>();
-    b.qkeys = nullptr; b.qkeys32 = nullptr; b.dir_ready = false;
+    b.qkeys = nullptr; b.qkeys32 = nullptr; b.dir_ready = false; b.k2_ready = false;
     idx->pending = *l;
     idx->receiving = true;
     memset(out, 0, sizeof *out);
@@ -484,6 +510,7 @@ int sa_hip_index_replica_commit(sa_hip_index* idx) {
     b.q_b = (int)l.bits_per_symbol; b.q_k0 = (int)l.initial_chars; b.q_dbits = (int)l.dir_bits; b.q_lo_shift = l.lo_shift;
     b.qkeys = l.key_bytes == 8 ? b.keys0.as<u64>() : nullptr;
     b.qkeys32 = l.key_bytes == 4 ? b.keys0.as<u32>() : nullptr;
+    b.k2_ready = false;
     b.dir_ready = l.key_bytes != 0;
     idx->has_index = true;
     return 0;
@@ -604,6 +631,29 @@ uint32_t sa_hip_index_max_suffix_length(const sa_hip_index* idx) { return idx ? 
 const void* sa_hip_index_text_dev(const sa_hip_index* idx) { return (idx && !idx->host) ? idx->b.text.p : nullptr; }
 const void* sa_hip_index_sa_dev(const sa_hip_index* idx) { return (idx && idx->has_index && !idx->host) ? idx->b.sa : nullptr; }
 void* sa_hip_index_stream(const sa_hip_index* idx) { return idx ? (void*)idx->stream : nullptr; }
+
+int sa_hip_index_deep_keys(sa_hip_index* idx, int mode) {
+    if (!idx || mode < 0 || mode > 2) return fail(SA_HIP_EINVAL, "sa_hip_index_deep_keys: invalid arguments");
+    if (idx->host) return 0;
+    std::lock_guard<std::mutex> lock(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    if (mode == 0) {   // never: drop them (8 n bytes back), large batches do not build them
+        SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+        idx->k2_auto = false;
+        idx->b.k2_ready = false;
+        idx->b.qkeys2.release();
+        idx->b.qskeys.release();
+        return 0;
+    }
+    idx->k2_auto = true;
+    if (mode == 2) {
+        if (!idx->has_index) return fail(SA_HIP_EINVAL, "sa_hip_index_deep_keys: no index");
+        if ((rc = ensure_k2(idx))) return rc;
+        SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+    }
+    return idx->b.k2_ready ? 1 : 0;
+}
 
 int sa_hip_index_sync(sa_hip_index* idx) {
     if (!idx) return fail(SA_HIP_EINVAL, "sa_hip_index_sync: NULL index");

@@ -114,7 +114,50 @@ struct QueryArgs {
     const u32* keys32;      // NARROW: K[j] = (top digit of j's directory bucket << 56) | (keys32[j] << lo_shift)
     int lo_shift;
     int sector_search;      // 1: interpolated sector scan inside the directory bucket (below), 64-byte windows; 2: 32-byte windows; 0: plain binary search
+    const u64* keys2;       // second-level keys (k2_build_kernel) or nullptr; wide keys only
+    const u64* skeys;       // every SKEY_STRIDE-th key of `keys` (with keys2) or nullptr
+    int k2n;                // characters a second-level key holds
 };
+
+// ---- second-level keys (round 4) ---------------------------------------------------------------------------------------------
+// A pattern longer than the key (k0 characters) leaves the slots that share its first k0 characters; the bounds inside that
+// range used to be found by comparing TEXT -- SA[mid], then the suffix there: two dependent random reads per step, and on
+// name-like text (every pattern a hit, popular prefixes shared by thousands of suffixes) that search was the whole batch:
+// 0.55 ms per 1e6 names, ~28 requests per query.  K2[j] = the k2n characters that follow the key of slot j (codes of b bits,
+// MSB first, left aligned; 0 past the end of the text or of a truncated index's depth), for every slot whose key equals a
+// neighbour's -- only those are ever inside a range of more than one slot.  Inside a key group the slots are in suffix order,
+// so K2 is sorted there: the bounds are two binary searches over 8-byte keys (one read per step, the last steps in one
+// sector), exact for patterns of up to k0 + k2n characters (23 at 5 bits), a narrower range for the text search beyond.
+__global__ __launch_bounds__(256) void k2_build_kernel(const u64* __restrict__ K, const u32* __restrict__ sa, const u8* __restrict__ text, u64 n,
+                                                       CodeMap map, int b, int k0, int k2n, u32 L, u64* __restrict__ K2) {
+    __shared__ u16 s_map[256];
+    s_map[threadIdx.x] = map.code[threadIdx.x];
+    __syncthreads();
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u32 depth = (L && L > (u32)k0) ? L - (u32)k0 : (L ? 0u : 0xFFFFFFFFu);   // characters beyond a truncated index's depth do not order anything
+    // a key group = the slots that share the key's first k0 CHARACTERS -- what a pattern's key range spans; the stored key may
+    // hold bits beyond them (10-byte-record plan: 55 bits of characters + one bit of the twelfth), which do not count here
+    const int gs = 64 - k0 * b;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const u64 k = K[j] >> gs;
+        const bool tied = (j > 0 && (K[j - 1] >> gs) == k) || (j + 1 < n && (K[j + 1] >> gs) == k);
+        if (!tied) continue;   // (never read: a slot alone in its key group is a range of one)
+        const u64 pos = (u64)sa[j] + (u64)k0;
+        u64 w[2] = {0, 0};
+        if (pos < n) { __builtin_memcpy(&w[0], text + pos, 8); __builtin_memcpy(&w[1], text + pos + 8, 8); }   // the text is zero padded: in bounds
+        u64 avail = pos < n ? n - pos : 0;
+        if (avail > depth) avail = depth;
+        u64 key = 0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c < k2n) {   // uniform
+                const u32 byte = (u32)(w[c >> 3] >> (8 * (c & 7))) & 255u;
+                key = (key << b) | (((u64)c < avail) ? (u64)s_map[byte] : 0ull);
+            }
+        }
+        K2[j] = key << (64 - k2n * b);
+    }
+}
 
 // The batch is bound by the NUMBER of 64-byte sectors it requests, not by bytes or by the dependent-load chain
 // (profiles/r02_a_pmc_*: 5.5 requests per query at the ~36 G requests/s the memory system sustains for random reads,
@@ -146,12 +189,22 @@ __device__ __forceinline__ void load_sector(const KT* __restrict__ K, u64 base, 
     }
 }
 // first slot in [l, h) with key >= t (STRICT: > t), starting at the sector of `est`; l < h
+// S (wide keys, with the second-level keys; nullptr otherwise): every SKEY_STRIDE-th key of K.  When the windows around the
+// estimate do not hold the bound -- on word / name text a directory bucket (the first 5.4 characters) can hold 10^7 slots and the
+// keys inside it are anything but uniformly spread -- the bisection runs over the SAMPLES first: log2(range / 256) reads of
+// an array that stays in the caches (116 MB at config-5 size with every 64th key), then at most 6 steps in K itself, instead of log2(range) reads
+// of K from DRAM.
+#ifndef SA_SKEY_STRIDE
+#define SA_SKEY_STRIDE 64
+#endif
+constexpr u64 SKEY_STRIDE = SA_SKEY_STRIDE;
 template <bool STRICT, typename KT, int WBYTES>
-__device__ __forceinline__ u64 sector_bound(const KT* __restrict__ K, u64 l, u64 h, KT t, u64 est, SectorWindow<KT, WBYTES>& w, bool have_window) {
+__device__ __forceinline__ u64 sector_bound(const KT* __restrict__ K, u64 l, u64 h, KT t, u64 est, SectorWindow<KT, WBYTES>& w, bool have_window,
+                                            const KT* __restrict__ S = nullptr, int window_steps = 3) {
     constexpr int W = SectorWindow<KT, WBYTES>::W;
     u64 lo = l, hi = h;   // the bound lies in [lo, hi]
     u64 base = est & ~(u64)(W - 1);
-    for (int step = 0; step < 3 && lo < hi; ++step) {
+    for (int step = 0; step < window_steps && lo < hi; ++step) {
         if (!(have_window && w.base == base)) load_sector(K, base, w);
         have_window = false;
         // slots of this sector inside [lo, hi)
@@ -175,12 +228,29 @@ __device__ __forceinline__ u64 sector_bound(const KT* __restrict__ K, u64 l, u64
             base += W;
         } else { lo = hi = a + below; }
     }
-    while (lo < hi) {   // rare: the estimate was more than two sectors off (long runs of equal keys, lumpy buckets)
+    if (S && hi - lo > 2 * SKEY_STRIDE) {
+        // first sample index i in [ia, ib) whose key is >= t (> t); sample i is slot i * SKEY_STRIDE, all of them inside [lo, hi)
+        u64 ia = (lo + SKEY_STRIDE - 1) / SKEY_STRIDE, ib = (hi - 1) / SKEY_STRIDE + 1;
+        const u64 ia0 = ia, ib0 = ib;
+        while (ia < ib) {
+            const u64 mid = (ia + ib) >> 1;
+            const KT k = S[mid];
+            if (STRICT ? (k <= t) : (k < t)) ia = mid + 1; else ib = mid;
+        }
+        if (ia < ib0) hi = ia * SKEY_STRIDE;             // that slot satisfies the bound's condition: the bound is at or before it
+        if (ia > ia0) lo = (ia - 1) * SKEY_STRIDE + 1;   // the sample before does not: the bound is after it
+    }
+    while (lo < hi) {   // (narrow keys: rare -- the estimate was more than two sectors off: long runs of equal keys, lumpy buckets)
         const u64 mid = (lo + hi) >> 1;
         const KT k = K[mid];
         if (STRICT ? (k <= t) : (k < t)) lo = mid + 1; else hi = mid;
     }
     return lo;
+}
+__global__ __launch_bounds__(256) void skeys_kernel(const u64* __restrict__ K, u64 n, u64* __restrict__ S) {
+    const u64 ns = (n + SKEY_STRIDE - 1) / SKEY_STRIDE;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += stride) S[i] = K[i * SKEY_STRIDE];
 }
 
 // MODE = QueryArgs::sector_search as a compile-time constant: the product path (2) does not carry the registers of the
@@ -205,8 +275,8 @@ __device__ __forceinline__ sa_hip_pair_u32 query_one(const QueryArgs& a, const u
         // ---- phase 1: narrow to the slots whose first P characters equal the pattern's -----------
         u64 lo = 0, hi = a.n;      // lb and ub both lie in [lo, hi]
         bool exact = false;        // the K range IS the answer (whole pattern packed)
+        int P = 0;                 // pattern characters the key search has matched
         if (K) {
-            int P = 0;
             u64 key_lo = 0;
             int sh = 64;
             const int pmax = (c < (u32)a.k0) ? (int)c : a.k0;
@@ -265,14 +335,19 @@ __device__ __forceinline__ sa_hip_pair_u32 query_one(const QueryArgs& a, const u
                         est = l + (((frac >> down) * (h - l)) >> (sb - down));
                         if (est >= h) est = h - 1;
                     }
+                    const KT* S = NARROW ? (const KT*)nullptr : reinterpret_cast<const KT*>(a.skeys);
                     if (MODE == 2) {   // 32-byte windows
                         SectorWindow<KT, 32> w;
-                        lo = sector_bound<false>(K, l, h, t_lo, est, w, false);
-                        hi = (lo < h) ? sector_bound<true>(K, lo, h, t_hi2, lo, w, true) : lo;
+                        // with sampled keys and a bucket far larger than a window the interpolated estimate is not worth its three
+                        // requests (text is not uniformly spread inside a bucket): samples first; the upper bound still looks at the
+                        // window the lower bound ended in (a small group ends there) and one more
+                        const bool big = S && h - l > 64 * SKEY_STRIDE;
+                        lo = sector_bound<false>(K, l, h, t_lo, est, w, false, S, big ? 0 : 3);
+                        hi = (lo < h) ? sector_bound<true>(K, lo, h, t_hi2, lo, w, !big, S, big ? 2 : 3) : lo;
                     } else {
                         SectorWindow<KT, 64> w;
-                        lo = sector_bound<false>(K, l, h, t_lo, est, w, false);
-                        hi = (lo < h) ? sector_bound<true>(K, lo, h, t_hi2, lo, w, true) : lo;
+                        lo = sector_bound<false>(K, l, h, t_lo, est, w, false, S);
+                        hi = (lo < h) ? sector_bound<true>(K, lo, h, t_hi2, lo, w, true, S) : lo;
                     }
                     searched = true;
                 }
@@ -295,6 +370,46 @@ __device__ __forceinline__ sa_hip_pair_u32 query_one(const QueryArgs& a, const u
                 hi = l2;
                 }
                 exact = ((u32)P == c);
+            }
+        }
+
+        // ---- phase 1b: second-level keys inside a key group of more than one slot (wide keys, when they have been built)
+        if (!NARROW && a.keys2 && !exact && hi - lo > 1 && P == a.k0) {
+            const int m2 = ((int)(c - (u32)a.k0) < a.k2n) ? (int)(c - (u32)a.k0) : a.k2n;   // >= 1: the pattern is longer than the key
+            u64 q2 = 0;
+            bool absent = false;   // a byte that does not occur in the text: nothing matches; the text search below says where
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i < m2) {
+                    const u32 x = (u32)a.k0 + (u32)i;
+                    u32 byte;
+                    if (x < 32u) {
+                        const u64 wsel = (x < 8u) ? qw[0] : (x < 16u) ? qw[1] : (x < 24u) ? qw[2] : qw[3];
+                        byte = (u32)(wsel >> (56u - 8u * (x & 7u))) & 255u;
+                    } else byte = q[x];
+                    const u32 code = s_map[byte];
+                    absent |= (code == 0);
+                    q2 = (q2 << a.b) | code;
+                }
+            }
+            if (!absent) {
+                const int sh2 = 64 - m2 * a.b;   // 4 <= sh2 < 64
+                const u64 q2_lo = q2 << sh2, q2_hi = q2_lo | ((1ull << sh2) - 1ull);
+                u64 l = lo, h = hi, h_strict = hi;   // the lower-bound descent remembers the tightest slot known to lie above the pattern
+                while (l < h) {
+                    const u64 mid = (l + h) >> 1;
+                    const u64 k2 = a.keys2[mid];
+                    if (k2 < q2_lo) l = mid + 1;
+                    else { h = mid; if (k2 > q2_hi) h_strict = mid; }
+                }
+                const u64 lb2 = l;
+                h = h_strict;
+                while (l < h) {
+                    const u64 mid = (l + h) >> 1;
+                    if (a.keys2[mid] <= q2_hi) l = mid + 1; else h = mid;
+                }
+                lo = lb2; hi = l;
+                exact = (c <= (u32)(a.k0 + a.k2n));
             }
         }
 

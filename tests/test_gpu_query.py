@@ -615,3 +615,69 @@ def test_fixed_length_batch_equals_offsets_batch(gpu, oracle):
                 b = out_b.cpu().numpy().view(np.uint32).reshape(-1, 2)
                 assert np.array_equal(a, b), (m, L)
                 assert np.array_equal(a[:, 0], exp["first"]) and np.array_equal(a[:, 1], exp["second"]), (m, L)
+
+
+def test_deep_keys_give_the_same_ranges(gpu, oracle, tmp_path):
+    """Second-level keys (round 4, sa_hip_index_prepare_deep_keys: the characters that follow the key, for the slots that share
+    their key with a neighbour): a pattern longer than the key finds its bounds inside a key group by a search over 8-byte keys
+    instead of text comparisons.  Name-like and word-like texts, full and truncated builds, an adopted index: the ranges with
+    and without them are identical and equal the oracle's -- whole names (all hit, many with thousands of hits), every prefix
+    length around the key and the second key (10..24 characters), names with a changed last character (misses inside a key
+    group), patterns longer than both keys, patterns with a byte that does not occur, patterns past the end of the text."""
+    from suffixarray_amd import synth
+    path = str(tmp_path / "companies.csv")
+    gpu.synth_csv(path, 60_000, 3)
+    names = np.array(gpu.csv_extract_column(path, "company_name", copy=False)[1])
+    words = synth.d2_words(1_200_000)
+    rng = np.random.default_rng(11)
+
+    def patterns(t):
+        ends = np.flatnonzero(t == 10)
+        pats = []
+        for j in rng.integers(1, ends.size, 1500):
+            a, b = int(ends[j - 1]) + 1, int(ends[j])
+            row = bytes(t[a:b])
+            if not row:
+                continue
+            pats.append(row)                                   # a whole row (name / line): hits
+            pats.append(row[:int(rng.integers(1, len(row) + 1))])   # a prefix of any length
+            if len(row) > 12:
+                pats.append(row[:-1] + bytes([(row[-1] + 1) & 0x7F or 65]))   # differs at its last character
+                pats.append(row[3:])                           # a suffix of the row: still a substring of the text
+            pats.append(row + b"\n" + bytes(t[b + 1:b + 1 + int(rng.integers(0, 20))]))   # across the row boundary: longer than both keys
+        for m in range(9, 26):                                 # windows of every length around the two key lengths
+            for p in rng.integers(0, t.size - 40, 40):
+                pats.append(bytes(t[p:p + m]))
+        pats += [b"zzzzzzzzzzzzzzzzzzzzzzzz", b"INTERNATIONAL \x01X", b"\xff" * 13, bytes(t[-5:]), bytes(t[-30:]) + b"tail", b"A"]
+        return pats
+
+    for name, t in (("names", names), ("words", words)):
+        pats = patterns(t)
+        for L in (32, 0, 15):
+            with gpu.DeviceIndex(t.size, 0) as idx:
+                idx.build(t, L)
+                st = idx.build_stats()
+                sa = idx.sa_u32().copy()
+                exp = oracle.query_batch(t, sa, L if L else 0xFFFFFFFF, pats)
+                plain = idx.query_batch(pats)
+                has = idx.prepare_deep_keys()
+                deep = idx.query_batch(pats)
+                assert np.array_equal(plain, exp), (name, L)
+                assert np.array_equal(deep, exp), (name, L, has)
+                assert has == (st["narrow_k"] == 0), (name, L, st["narrow_k"])   # wide keys: built; narrow keys: no use for them
+                # an adopted index (keys gathered from the text) answers the same way with them
+                if L == 32:
+                    with gpu.DeviceIndex(t.size, 0) as idx2:
+                        idx2.load(t, sa, L)
+                        assert idx2.prepare_deep_keys()
+                        assert np.array_equal(idx2.query_batch(pats), exp), (name, "adopted")
+    # a batch of at least 32768 patterns builds them on its way; the rebuilt index drops them again
+    big = patterns(names)
+    big = (big * (32768 // len(big) + 1))[:40000]
+    with gpu.DeviceIndex(names.size, 0) as idx:
+        idx.build(names, 32)
+        sa = idx.sa_u32().copy()
+        got = idx.query_batch(big)
+        assert np.array_equal(got, oracle.query_batch(names, sa, 32, big))
+        idx.build(names, 32)
+        assert np.array_equal(idx.query_batch(big[:500]), got[:500])

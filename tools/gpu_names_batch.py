@@ -25,12 +25,23 @@ lens = (b - a).astype(np.uint64)
 off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
 src = np.repeat(a - off[:-1].astype(np.int64), lens.astype(np.int64)) + np.arange(int(off[-1]), dtype=np.int64)
 buf = col[src]
+import time
 with _capi.DeviceIndex(col.size, 0) as idx:
     idx.build(col, 32)
+    idx.deep_keys(0)   # text comparisons inside a key group (round 3's search)
+    ms0 = []
+    for _ in range(3):
+        res0 = idx.query_batch((buf, off))
+        ms0.append(idx.query_stats()["kernel_ms"])
+    t0 = time.perf_counter()
+    has = idx.deep_keys(2)   # second-level keys (round 4)
+    k2_ms = (time.perf_counter() - t0) * 1e3
     ms = []
     for _ in range(3):
         res = idx.query_batch((buf, off))
         ms.append(idx.query_stats()["kernel_ms"])
+    print("without deep keys: kernel %.3f ms (%.2f G queries/s); deep keys built=%s in %.1f ms (host clock); same ranges: %s" % (
+        min(ms0), a.size / min(ms0) / 1e6, has, k2_ms, bool(np.array_equal(res, res0))))
 cnt = ((res["second"].astype(np.int64) - res["first"].astype(np.int64) + 1) & 0xFFFFFFFF)
 cnt[res["first"] == 0xFFFFFFFF] = 0
 print("names batch: %d queries, mean length %.1f, kernel %.3f ms (%.2f G queries/s), hit rate %.3f, hits mean %.0f median %.0f p90 %.0f p99 %.0f" % (
