@@ -257,6 +257,8 @@ def config5_csv(_capi, rows=50_000_000, budget_s=12.0):
         # the column itself (one name per '\n'-terminated row) feeds the two measurements below
         col = idx.text()
         out["names_batch_1e6"] = names_batch(idx, col, rng)
+        # a batch large enough for the clustering of round 4 (from 2^20 patterns on: answered in the order of the patterns' first characters)
+        out["names_batch_8e6"] = names_batch(idx, col, rng, q=8_000_000)
         s.close()
         del s, idx
         out["documents_5M"] = documents_protocol(col, rng)

@@ -11,13 +11,15 @@ sys.path.insert(0, ROOT)
 from suffixarray_amd import _capi  # noqa: E402
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
+Q = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+SORTED = (int(sys.argv[3]) if len(sys.argv) > 3 else 1) != 0
 path = "/tmp/companies_%d.csv" % rows
 _capi.synth_csv(path, rows, 1)
 col = np.array(_capi.csv_extract_column(path, "company_name", copy=False)[1])
 os.remove(path)
 rng = np.random.default_rng(0)
 ends = np.flatnonzero(col == 10)
-pick = np.sort(rng.integers(1, ends.size, 1_000_000))
+pick = np.sort(rng.integers(1, ends.size, Q))
 a, b = ends[pick - 1] + 1, ends[pick]
 keep = b > a
 a, b = a[keep], b[keep]
@@ -40,6 +42,20 @@ with _capi.DeviceIndex(col.size, 0) as idx:
     for _ in range(3):
         res = idx.query_batch((buf, off))
         ms.append(idx.query_stats()["kernel_ms"])
+    # the same patterns in lexicographic order (what a caller -- or the library -- could do before the launch): lanes of a wave
+    # then walk the same key groups
+    if SORTED:
+      pats = [bytes(col[x:y]) for x, y in zip(a, b)]
+      order = sorted(range(len(pats)), key=pats.__getitem__)
+      lens_s = lens[order]
+      off_s = np.concatenate([[0], np.cumsum(lens_s)]).astype(np.uint64)
+      buf_s = np.frombuffer(b"".join(pats[i] for i in order), np.uint8)
+      ms_s = []
+      for _ in range(3):
+        res_s = idx.query_batch((buf_s, off_s))
+        ms_s.append(idx.query_stats()["kernel_ms"])
+      print("patterns sorted lexicographically: kernel %.3f ms (%.2f G queries/s); same ranges: %s" % (
+        min(ms_s), a.size / min(ms_s) / 1e6, bool(np.array_equal(res_s, res[order]))))
     print("without deep keys: kernel %.3f ms (%.2f G queries/s); deep keys built=%s in %.1f ms (host clock); same ranges: %s" % (
         min(ms0), a.size / min(ms0) / 1e6, has, k2_ms, bool(np.array_equal(res, res0))))
 cnt = ((res["second"].astype(np.int64) - res["first"].astype(np.int64) + 1) & 0xFFFFFFFF)
