@@ -490,6 +490,59 @@ __global__ __launch_bounds__(FIN_BLOCK, FIN_BLOCK == 512 ? 4 : 2) void group_fin
     }
 }
 
+// ---- what a finisher run leaves behind, without a pass over the list (round 4) ------------------------------------------------
+// When no tile gave up on a group, the records a run leaves are exactly the groups its plan left out: records [local_end, end)
+// of every tile, one group each (round_sort.hpp: LocTile).  The next lists are then a copy of those ranges -- work in proportion
+// to what is LEFT (config 5: 56 M of 530 M records) -- instead of done flags for all M records, a flags pass, a scan and a
+// compaction over them.  left_scan_kernel: exclusive prefixes of the ranges' sizes (into LocTile::big_off) and of the non-empty
+// ranges (the next dense group ids), totals {records, groups}; left_copy_kernel: the ranges to the next lists.
+__global__ __launch_bounds__(1024) void left_scan_kernel(LocTile* __restrict__ tiles, u32 ntiles, u32* __restrict__ next_gid, u32* __restrict__ totals) {
+    __shared__ u32 s_a[16], s_b[16];
+    __shared__ u32 s_ca, s_cb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_ca = 0; s_cb = 0; }
+    __syncthreads();
+    for (u32 base = 0; base < ntiles; base += 1024) {
+        const u32 t = base + threadIdx.x;
+        const u32 va = (t < ntiles) ? tiles[t].end - tiles[t].local_end : 0u;
+        const u32 vb = va ? 1u : 0u;
+        u32 ia = va, ib = vb;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 xa = __shfl_up(ia, o), xb = __shfl_up(ib, o);
+            if (lane >= o) { ia += xa; ib += xb; }
+        }
+        if (lane == 63) { s_a[wave] = ia; s_b[wave] = ib; }
+        __syncthreads();
+        u32 oa = s_ca, ob = s_cb;
+        for (int w = 0; w < wave; ++w) { oa += s_a[w]; ob += s_b[w]; }
+        if (t < ntiles) { tiles[t].big_off = oa + ia - va; next_gid[t] = ob + ib - vb; }
+        __syncthreads();
+        if (threadIdx.x == 1023) { s_ca = oa + ia; s_cb = ob + ib; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { totals[0] = s_ca; totals[1] = s_cb; }
+}
+__global__ __launch_bounds__(256) void left_copy_kernel(const LocTile* __restrict__ tiles, u32 ntiles, const u32* __restrict__ next_gid,
+                                                        const u32* __restrict__ apos, const u32* __restrict__ aidx, u32* __restrict__ out_apos,
+                                                        u32* __restrict__ out_aidx, u32* __restrict__ out_gid) {
+    for (u32 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const LocTile lt = tiles[t];
+        const u32 cnt = lt.end - lt.local_end;
+        if (cnt == 0) continue;
+        const u32 per = (cnt + gridDim.y - 1) / gridDim.y;
+        const u32 lo = blockIdx.y * per;
+        const u32 hi = (lo + per < cnt) ? lo + per : cnt;
+        const u32 g = next_gid[t];
+        for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            const u64 r = (u64)lt.local_end + i, l = (u64)lt.big_off + i;
+            out_apos[l] = apos[r];
+            out_aidx[l] = aidx[r];
+            out_gid[l] = g;
+        }
+    }
+}
+
 // ---- round 4: the finisher restructured (SA_HIP_FIN_V2=1; NOT the default) ---------------------------------------------------------
 // MEASURED (profiles/r04_finisher_v2_ab.log): bit-identical to the kernel above on every test and no faster -- names 2e8 13.5 vs
 // 13.5 ms, words 1e8 10.1 vs 10.1, the config-5 column 62.6-62.9 vs 61.4 ms.  The counters say why: both kernels issue the same

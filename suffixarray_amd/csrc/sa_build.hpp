@@ -1161,6 +1161,9 @@ struct Builder {
     bool local_rounds = true;         // SA_HIP_LOCAL_ROUNDS: rounds sorted group-wise in LDS (round_sort.hpp)
     DevBuf gstart, loc_tiles, big_keys, big_vals;
     bool group_finish = true;         // SA_HIP_GROUP_FINISH: groups that fit a tile are refined to the end in LDS (group_finish.hpp)
+    bool fin_left_failed = false;     // this build: a finisher run has given up on a group (the shortcut below is not tried again)
+    bool fin_left_fast = true;        // SA_HIP_FIN_LEFT_FAST=0: what a finisher run leaves is always found from the done flags (flags pass + scan + compaction over the list)
+    DevBuf fin_left_gid;              // u32[tiles]: next dense group id of a tile's left-out group
     bool fin_prefetch = false;        // SA_HIP_FIN_PREFETCH=1: the finisher's first-round text fetches as a kernel of their own (measured slower: the gather costs what it saves)
     bool fin_v2 = false;              // SA_HIP_FIN_V2=1: round 4's restructured finisher (group_finish2_kernel); measured 0-2 % SLOWER than the round-2 kernel
                                       // (profiles/r04_finisher_v2_ab.log), so it is not the default
@@ -1278,6 +1281,7 @@ struct Builder {
         if (const char* e = diag_env("SA_HIP_LOCAL_ROUNDS")) local_rounds = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_GROUP_FINISH")) group_finish = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_FIN_V2")) fin_v2 = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_FIN_LEFT_FAST")) fin_left_fast = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_FIN_PREFETCH")) fin_prefetch = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_PILOT")) use_pilot = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_PERIOD_FINISH")) period_finish = atoi(e) != 0;
@@ -1315,7 +1319,7 @@ struct Builder {
     void destroy() {
         DevBuf* all[] = {&text, &keys0, &keys1, &vals0, &vals1, &flags, &counts, &small, &isa, &apos0, &apos1, &apos2, &aidx,
                          &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir, &dbg, &done, &pilot,
-                         &gstart, &loc_tiles, &big_keys, &big_vals, &fin_flag, &fin_w0, &qkeys2, &qskeys, &per_gd, &per_bad, &per_table, &per_dec, &per_tf, &per_carry};
+                         &gstart, &loc_tiles, &big_keys, &big_vals, &fin_flag, &fin_w0, &fin_left_gid, &qkeys2, &qskeys, &per_gd, &per_bad, &per_table, &per_dec, &per_tf, &per_carry};
         for (DevBuf* b : all) b->release();
         radix.destroy();
         narrow.destroy();
@@ -1744,6 +1748,45 @@ struct Builder {
         else hipLaunchKernelGGL(group_finish_kernel, dim3(ntiles), dim3(FIN_BLOCK), 0, stream, a, map);
         unsigned long long ft_host[32] = {0};
         SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_FT, ft, 256, hipMemcpyDeviceToHost, stream));
+        // What the run leaves.  When no tile gave up (every record inside the tiles was resolved: totals[0] == totals[1]) that is
+        // exactly the groups the plan left out -- copied to the next lists, speculatively, before the totals are known: one
+        // synchronisation either way.  Otherwise (long repeats) the done flags decide, as before.
+        bool left_fast = false;
+        u32 left_host[2] = {0, 0};
+        if (fin_left_fast && ntiles > 1 && !fin_left_failed) {
+            // the sizes of what the plan left out (one small workgroup) travel with the finisher's totals: one synchronisation;
+            // the copy itself only when it is known to be the whole story
+            u32* left_tot = reinterpret_cast<u32*>(small.as<u8>() + 3632);
+            if ((rc = fin_left_gid.ensure((size_t)ntiles * 4 + 64))) return rc;
+            hipLaunchKernelGGL(left_scan_kernel, dim3(1), dim3(1024), 0, stream, loc_tiles.as<LocTile>(), ntiles, fin_left_gid.as<u32>(), left_tot);
+            SA_HIP_CHECK(hipMemcpyAsync(mbox + MB_BIG, left_tot, 8, hipMemcpyDeviceToHost, stream));
+            SA_HIP_CHECK(hipStreamSynchronize(stream));
+            memcpy(ft_host, mbox + MB_FT, 256);
+            memcpy(left_host, mbox + MB_BIG, 8);
+            left_fast = ft_host[0] == ft_host[1] && (u64)ft_host[0] + left_host[0] == M;
+            if (left_fast && left_host[0]) {
+                const u32 cg = ntiles < 2048u ? ntiles : 2048u;
+                // (ridx0 was the kernel's scratch and is free again; ridx1 holds 4 bytes per record of the first list like ridx0)
+                hipLaunchKernelGGL(left_copy_kernel, dim3(cg, 16), dim3(256), 0, stream, (const LocTile*)loc_tiles.as<LocTile>(), ntiles,
+                                   (const u32*)fin_left_gid.as<u32>(), (const u32*)apos_cur, (const u32*)aidx.as<u32>(), apos_nxt, ridx0.as<u32>(), ridx1.as<u32>());
+            }
+            if (!left_fast) fin_left_failed = true;   // a text whose groups defeat the finisher (long repeats) does so in every run: no second attempt in this build
+        }
+        if (left_fast) {
+            tot[0] = left_host[0]; tot[1] = left_host[1];
+            if (tot[0]) {
+                SA_HIP_CHECK(hipMemcpyAsync(aidx.p, ridx0.p, (size_t)tot[0] * 4, hipMemcpyDeviceToDevice, stream));
+                SA_HIP_CHECK(hipMemcpyAsync(gid.p, ridx1.p, (size_t)tot[0] * 4, hipMemcpyDeviceToDevice, stream));
+                swap_lists();
+            }
+            stats.finisher_runs += 1;
+            stats.finisher_records += ft_host[0];
+            stats.finisher_resolved += (u64)M - tot[0];
+            if (ft_host[1] * 4 < ft_host[0]) fin_useful = false;
+            M = tot[0];
+            G = tot[1];
+            return 0;
+        }
         const u32 tiles = div_up(M, BLD_TILE);
         hipLaunchKernelGGL(tiny_flags_kernel, dim3(tiles), dim3(BLD_BLOCK), 0, stream, gid.as<u32>(), done.as<u8>(), M, lf.as<u8>(),
                            counts.as<uint2>());
@@ -1851,6 +1894,7 @@ struct Builder {
         memset(&stats, 0, sizeof stats);
         local_records = big_records = 0;
         fin_useful = true;
+        fin_left_failed = false;
         per_skip = per_fails = 0;
         radix.reset_stats();
         max_suffix_length = L;
