@@ -1,4 +1,5 @@
-"""The names batch of bench.py (secondary.config5_csv_50M_rows.names_batch_1e6) on its own, for counter runs:
+"""The names batch of bench.py (secondary.config5_csv_50M_rows.names_batch_1e6 / _8e6) on its own, for counter runs and A/B:
+    python3 tools/gpu_names_batch.py [rows] [queries] [also_presorted: 1 / 0]
     rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d gpurun_out/pmc_names -- python3 tools/gpu_names_batch.py [rows]
 builds the company_name column index (L = 32) and answers 1e6 sampled names three times; prints kernel time and hit statistics."""
 import os
@@ -45,17 +46,17 @@ with _capi.DeviceIndex(col.size, 0) as idx:
     # the same patterns in lexicographic order (what a caller -- or the library -- could do before the launch): lanes of a wave
     # then walk the same key groups
     if SORTED:
-      pats = [bytes(col[x:y]) for x, y in zip(a, b)]
-      order = sorted(range(len(pats)), key=pats.__getitem__)
-      lens_s = lens[order]
-      off_s = np.concatenate([[0], np.cumsum(lens_s)]).astype(np.uint64)
-      buf_s = np.frombuffer(b"".join(pats[i] for i in order), np.uint8)
-      ms_s = []
-      for _ in range(3):
-        res_s = idx.query_batch((buf_s, off_s))
-        ms_s.append(idx.query_stats()["kernel_ms"])
-      print("patterns sorted lexicographically: kernel %.3f ms (%.2f G queries/s); same ranges: %s" % (
-        min(ms_s), a.size / min(ms_s) / 1e6, bool(np.array_equal(res_s, res[order]))))
+        pats = [bytes(col[x:y]) for x, y in zip(a, b)]
+        order = sorted(range(len(pats)), key=pats.__getitem__)
+        lens_s = lens[order]
+        off_s = np.concatenate([[0], np.cumsum(lens_s)]).astype(np.uint64)
+        buf_s = np.frombuffer(b"".join(pats[i] for i in order), np.uint8)
+        ms_s = []
+        for _ in range(3):
+            res_s = idx.query_batch((buf_s, off_s))
+            ms_s.append(idx.query_stats()["kernel_ms"])
+        print("patterns sorted lexicographically: kernel %.3f ms (%.2f G queries/s); same ranges: %s" % (
+            min(ms_s), a.size / min(ms_s) / 1e6, bool(np.array_equal(res_s, res[order]))))
     print("without deep keys: kernel %.3f ms (%.2f G queries/s); deep keys built=%s in %.1f ms (host clock); same ranges: %s" % (
         min(ms0), a.size / min(ms0) / 1e6, has, k2_ms, bool(np.array_equal(res, res0))))
 cnt = ((res["second"].astype(np.int64) - res["first"].astype(np.int64) + 1) & 0xFFFFFFFF)
