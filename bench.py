@@ -462,6 +462,9 @@ def run_single(args, torch, _capi, synth, dev, device):
     queries_per_s = Q * steps / (query_ms / 1e3)
     if last.get("text_top_pass"):
         PASS_KERNELS[1] = "text_top_pass_kernel<512>"
+    if last.get("split_plan"):   # the three-pass plan (radix_split.hpp): kinds 2 / 3 are its two launches
+        PASS_KERNELS[2] = "seg_split_kernel<512, 24>"
+        PASS_KERNELS[3] = "local_finish_kernel"
     # dominant kernel = the sort-pass kernel with the largest share of the timed region
     dom = max(range(4), key=lambda k: kind_ms[k])
     pass_ms = kind_ms[dom] / max(kind_launches[dom], 1)
@@ -517,7 +520,8 @@ def run_single(args, torch, _capi, synth, dev, device):
         "queries_per_s": queries_per_s,
         "query_ms": query_ms / steps,
         "build_stats": {k: last[k] for k in ("sigma", "bits_per_symbol", "initial_chars", "rounds", "chunk_rounds",
-                                             "doubling_rounds", "final_depth", "radix_passes", "active_total", "narrow_k")},
+                                             "doubling_rounds", "final_depth", "radix_passes", "active_total", "narrow_k",
+                                             "split_plan", "split_max")},
         "roofline": {"bound": "hbm", "kernel": PASS_KERNELS[dom], "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK,
                      # PMC passes cannot run inside this process: `traffic` is REPLAYED from the committed counter run of the same
@@ -533,7 +537,7 @@ def run_single(args, torch, _capi, synth, dev, device):
                                                         "bytes_per_launch": kind_bytes[k] / kind_launches[k],
                                                         "achieved": kind_bytes[k] / kind_ms[k] / 1e6}
                                       for k in range(4) if kind_launches[k]}},
-        "widen": ({"fused": True, "note": "int64 stores in seg_onesweep_kernel<512, 24, true, true> (8 more bytes per record) + a patch of the refined slots"}
+        "widen": ({"fused": True, "note": ("int64 stores in local_finish_kernel" if last.get("split_plan") else "int64 stores in seg_onesweep_kernel<512, 24, true, true>") + " (8 more bytes per record) + a patch of the refined slots"}
                   if last.get("widen_fused") else
                   {"fused": False, "bytes_per_launch": 12.0 * N, "avg_launch_ms": widen_ms / steps,
                    "achieved": 12.0 * N * steps / (widen_ms / 1e3) / 1e9 if widen_ms > 0 else None, "unit": "GB/s"}),

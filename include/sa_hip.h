@@ -416,6 +416,10 @@ typedef struct sa_hip_build_stats {
                                   *    text_top_pass_kernel<512, true>, [2] / [3] = seg48_onesweep_kernel                           */
     uint32_t lite_flags;         /* 1: the first flags pass wrote no flag array (near-random text: active records staged per tile)  */
     uint64_t period_resolved;    /* suffixes ordered by the periodic-run shortcut (long repeats: period_finish.hpp)              */
+    uint32_t split_plan;         /* > 0 (= rb, the key bits of the split): the narrow sort ran as THREE passes over the records (radix_split.hpp): kernels [2] = seg_split_kernel<512,24>
+                                  *    (one launch: the records of a bucket grouped by their next rb <= 10 key bits), [3] = local_finish_kernel (one
+                                  *    launch: every group ordered completely in LDS, suffixes out as u32 and, for a 64-bit build, int64)        */
+    uint32_t split_max;          /* largest group at the level taken (declined: at the finest level, > 8192); 0: the plan was not considered      */
 } sa_hip_build_stats;
 int sa_hip_index_build_stats(const sa_hip_index* idx, sa_hip_build_stats* out);
 

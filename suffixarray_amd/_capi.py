@@ -61,7 +61,7 @@ class BuildStats(C.Structure):
                 ("text_top_pass", C.c_uint32), ("narrow_k", C.c_uint32), ("widen_ms", C.c_double),
                 ("finisher_records", C.c_uint64), ("finisher_resolved", C.c_uint64), ("finisher_runs", C.c_uint32),
                 ("widen_fused", C.c_uint32), ("narrow48", C.c_uint32), ("lite_flags", C.c_uint32),
-                ("period_resolved", C.c_uint64)]
+                ("period_resolved", C.c_uint64), ("split_plan", C.c_uint32), ("split_max", C.c_uint32)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if k.startswith("pass_") else getattr(self, k)) for k, _ in self._fields_}

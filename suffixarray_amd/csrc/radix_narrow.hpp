@@ -28,6 +28,7 @@
 // the next pass is one LDS histogram per tile added to hist_next[b][.].
 #pragma once
 #include "radix_sort.hpp"
+#include <vector>
 
 namespace sa {
 
@@ -374,6 +375,10 @@ __global__ __launch_bounds__(BLOCK, (ITEMS > 16) ? 4 : (LATEV ? 6 : 4)) void seg
     else
         seg_tile<false, BLOCK, ITEMS, LAST, LATEV>(a, flat, first_flat, bucket, start, rest, s_keys, s_whist, s_gdelta, s_wsum);
 }
+
+}  // namespace sa
+#include "radix_split.hpp"   // the three-pass plan: split pass + local finish (uses SegPlan / seg_bucket_of above)
+namespace sa {
 
 // ---- histogram of the top digit, per chunk of the input order, straight from the text -----------------------
 // hist[chunk][d], d = top 8 bits of the key of every position = its first c8 = ceil(8 / b) characters.  Every
@@ -927,6 +932,22 @@ struct NarrowWorkspace {
     u32* tickets = nullptr;  // [NARROW_MAX_PASSES][NCHUNK]
     u16* map_dev = nullptr;  // CodeMap of the text pass
     CodeMap map_host;        // source of the asynchronous copy (must outlive the call)
+    // the three-pass plan (radix_split.hpp)
+    bool split_enabled = true;     // SA_HIP_SPLIT=0: always the LSD passes
+    bool split_used = false;       // of the last sort
+    u32 split_max_seen = 0;        // largest sub-bucket of the last sort that looked (0: the plan was not considered)
+    u32* split_hist = nullptr;     // [RADIX][SPLIT_NB]
+    u32* split_base = nullptr;     // [RADIX][SPLIT_NB]
+    u32* split_sub = nullptr;      // [(RADIX << SPLIT_BITS) + 1] sub-bucket starts | [16] largest group per level
+    u64* split_status = nullptr;   // [split_tiles][SPLIT_NB], allocated with the first sort that takes the plan
+    u32 split_tiles = 0;
+    u32 split_epoch = 0;           // epoch of the last split pass (the granules are re-zeroed when the sort's epoch has wrapped)
+    u32* host_word = nullptr;      // pinned, 16 words: the largest group per level comes here
+    static size_t split_table_bytes() { return (size_t)RADIX * SPLIT_NB * sizeof(u32); }
+    static size_t split_sub_words() { return ((size_t)RADIX << SPLIT_BITS) + 1; }
+    u32* split_levels_dev() const { return split_sub + split_sub_words(); }   // [16]: largest group per level
+    u32 split_cap = LOCAL_CAP;     // SA_HIP_SPLIT_CAP (tests: a smaller bound makes small texts take more levels)
+    int split_rb = 0;              // level of the last sort that took the plan
     static size_t hist_bytes() { return (size_t)NARROW_MAX_PASSES * RADIX * RADIX * sizeof(u32); }
     int init() {
         SA_HIP_CHECK(hipMalloc(&plan, sizeof(SegPlan)));
@@ -934,6 +955,23 @@ struct NarrowWorkspace {
         SA_HIP_CHECK(hipMalloc(&base, (size_t)RADIX * RADIX * sizeof(u32)));
         SA_HIP_CHECK(hipMalloc(&tickets, (size_t)NARROW_MAX_PASSES * NCHUNK * sizeof(u32)));
         SA_HIP_CHECK(hipMalloc(&map_dev, sizeof(CodeMap)));
+        SA_HIP_CHECK(hipMalloc(&split_hist, split_table_bytes()));
+        SA_HIP_CHECK(hipMalloc(&split_base, split_table_bytes()));
+        SA_HIP_CHECK(hipMalloc(&split_sub, (split_sub_words() + 16) * sizeof(u32)));
+        SA_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host_word), 64, hipHostMallocDefault));
+        if (const char* e = diag_env("SA_HIP_SPLIT")) split_enabled = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_SPLIT_CAP")) { const int v = atoi(e); if (v >= 64 && v <= (int)LOCAL_CAP) split_cap = (u32)v; }
+        return 0;
+    }
+    // (zeroed ON THE SORT'S STREAM: a hipMemset on the null stream is not ordered against a non-blocking stream and was still
+    //  clearing granules while the split pass published them)
+    int ensure_split_status(u32 tiles, hipStream_t stream) {
+        if (tiles <= split_tiles) return 0;
+        if (split_status) { SA_HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(split_status); }
+        split_status = nullptr; split_tiles = 0;
+        SA_HIP_CHECK(hipMalloc(&split_status, (size_t)tiles * SPLIT_NB * sizeof(u64)));
+        SA_HIP_CHECK(hipMemsetAsync(split_status, 0, (size_t)tiles * SPLIT_NB * sizeof(u64), stream));
+        split_tiles = tiles;
         return 0;
     }
     void destroy() {
@@ -942,8 +980,14 @@ struct NarrowWorkspace {
         if (base) (void)hipFree(base);
         if (tickets) (void)hipFree(tickets);
         if (map_dev) (void)hipFree(map_dev);
+        if (split_hist) (void)hipFree(split_hist);
+        if (split_base) (void)hipFree(split_base);
+        if (split_sub) (void)hipFree(split_sub);
+        if (split_status) (void)hipFree(split_status);
+        if (host_word) (void)hipHostFree(host_word);
         map_dev = nullptr;
         plan = nullptr; hist = nullptr; base = nullptr; tickets = nullptr;
+        split_hist = split_base = split_sub = nullptr; split_status = nullptr; split_tiles = 0; host_word = nullptr;
     }
 };
 
@@ -1064,7 +1108,91 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
     const u32 seg_tile_n = 512u * SEG_ITEMS;
     hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(256), 0, stream, ws.hist(0), seg_tile_n, nw.plan);
     const u32 flat_max = n / seg_tile_n + 1 + RADIX;   // >= sum over buckets of ceil(size / tile)
-    // narrow keys now in keysB (u32), values in valsB; histogram of the first narrow digit per bucket
+    // narrow keys now in keysB (u32), values in valsB.
+    // Three-pass plan (radix_split.hpp): the records of a bucket are grouped by their next rb key bits, then every group is
+    // ordered completely in LDS -- when the largest group fits (near-random text; the device's own count decides)
+    nw.split_used = false;
+    nw.split_max_seen = 0;
+    if (nw.split_enabled && keep_narrow && ws.block == 512 && lo_bits - LOCAL_BIN_BITS >= 1) {
+        const int hb = (lo_bits - LOCAL_BIN_BITS < SPLIT_BITS) ? lo_bits - LOCAL_BIN_BITS : SPLIT_BITS;   // key bits the histogram looks at
+        SA_HIP_CHECK(hipMemsetAsync(nw.split_hist, 0, NarrowWorkspace::split_table_bytes(), stream));
+        SA_HIP_CHECK(hipMemsetAsync(nw.split_levels_dev(), 0, 16 * sizeof(u32), stream));
+        const u32 tpb = 4;
+        hipLaunchKernelGGL((split_hist_kernel<512, SEG_ITEMS>), dim3(div_up(flat_max, tpb)), dim3(512), 0, stream,
+                           reinterpret_cast<const u32*>(keysB), nw.plan, lo_bits - hb, (1u << hb) - 1u, nw.split_hist, tpb);
+        hipLaunchKernelGGL(split_levels_kernel, dim3(RADIX), dim3(SPLIT_NB), 0, stream, (const u32*)nw.split_hist, hb, nw.split_levels_dev());
+        SA_HIP_CHECK(hipMemcpyAsync(nw.host_word, nw.split_levels_dev(), 16 * sizeof(u32), hipMemcpyDeviceToHost, stream));
+        SA_HIP_CHECK(hipStreamSynchronize(stream));
+        int rb = -1;
+        for (int k = 1; k <= hb; ++k)
+            if (nw.host_word[k] <= nw.split_cap) { rb = k; break; }
+        nw.split_max_seen = nw.host_word[rb > 0 ? rb : hb];
+        if (rb > 0) {
+            const int rest_bits = lo_bits - rb;   // >= LOCAL_BIN_BITS
+            const int dshift = lo_bits - rb;
+            const u32 dmask = (1u << rb) - 1u;
+            hipLaunchKernelGGL(split_scan_kernel, dim3(RADIX), dim3(SPLIT_NB), 0, stream, (const u32*)nw.split_hist, nw.plan, hb, rb,
+                               nw.split_base, nw.split_sub);
+            if ((rc = nw.ensure_split_status(flat_max, stream))) return rc;
+            if (++ws.epoch >= (1u << 30)) {
+                SA_HIP_CHECK(hipMemsetAsync(ws.status, 0, (size_t)ws.max_tiles * RADIX * sizeof(u64), stream));
+                ws.epoch = 1;
+            }
+            if (ws.epoch <= nw.split_epoch)   // the sort's epoch has wrapped since the last split pass
+                SA_HIP_CHECK(hipMemsetAsync(nw.split_status, 0, (size_t)nw.split_tiles * SPLIT_NB * sizeof(u64), stream));
+            nw.split_epoch = ws.epoch;
+            SplitPassArgs a;
+            a.keys_in = reinterpret_cast<const u32*>(keysB); a.vals_in = valsB;
+            a.keys_out = reinterpret_cast<u32*>(keysA); a.vals_out = valsA;
+            a.plan = nw.plan; a.shift = dshift; a.mask = dmask; a.digit_base = nw.split_base; a.status = nw.split_status;
+            a.ticket = nw.tickets; a.epoch = ws.epoch; a.dstat = ws.dstat; a.incl_mask = SA_INCL_MASK;
+            if ((rc = ws.timer.start(stream, 2))) return rc;
+            hipLaunchKernelGGL((seg_split_kernel<512, SEG_ITEMS>), dim3(flat_max), dim3(512), 0, stream, a);
+            if ((rc = ws.timer.stop(stream, (u64)n * 16u))) return rc;
+            ws.pass_records += n; ws.pass_bytes += (u64)n * 16u; ws.passes += 1;
+            LocalArgs l;
+            l.keys_in = reinterpret_cast<const u32*>(keysA); l.vals_in = valsA;
+            l.keys_out = reinterpret_cast<u32*>(keysB); l.vals_out = valsB; l.vals_out64 = vals_res64;
+            l.sub = nw.split_sub;
+            l.bin_shift = rest_bits - LOCAL_BIN_BITS; l.bin_mask = (u32)LOCAL_NBINS - 1u;
+            l.dstat = ws.dstat;
+            const u64 local_bytes = (u64)n * 16u + (vals_res64 ? (u64)n * 8u : 0u);
+            if ((rc = ws.timer.start(stream, 3))) return rc;
+            hipLaunchKernelGGL(local_finish_kernel, dim3((u32)RADIX << rb), dim3(LOCAL_BLOCK), 0, stream, l);
+            if ((rc = ws.timer.stop(stream, local_bytes))) return rc;
+            ws.pass_records += n; ws.pass_bytes += local_bytes; ws.passes += 1;
+            SA_HIP_CHECK(hipGetLastError());
+            if (diag_env("SA_HIP_SPLIT_DEBUG")) {   // diagnostic: both passes checked on the host
+                const u32 nsub = (u32)RADIX << rb;
+                std::vector<u32> sub(nsub + 1), k1(n), k2(n), v2(n), bst(RADIX + 1);
+                SA_HIP_CHECK(hipStreamSynchronize(stream));
+                SA_HIP_CHECK(hipMemcpy(sub.data(), nw.split_sub, (size_t)(nsub + 1) * 4, hipMemcpyDeviceToHost));
+                SA_HIP_CHECK(hipMemcpy(k1.data(), keysA, (size_t)n * 4, hipMemcpyDeviceToHost));
+                SA_HIP_CHECK(hipMemcpy(k2.data(), keysB, (size_t)n * 4, hipMemcpyDeviceToHost));
+                SA_HIP_CHECK(hipMemcpy(v2.data(), valsB, (size_t)n * 4, hipMemcpyDeviceToHost));
+                SA_HIP_CHECK(hipMemcpy(bst.data(), nw.plan->bstart, (size_t)(RADIX + 1) * 4, hipMemcpyDeviceToHost));
+                u64 bad_sub = 0, bad_split = 0, bad_sorted = 0, bad_mono = 0;
+                u32 first_split = ~0u, first_sorted = ~0u;
+                for (u32 i = 0; i < nsub; ++i) {
+                    if (sub[i] > sub[i + 1] || sub[i + 1] > n) { ++bad_mono; continue; }
+                    if ((i & (((u32)1 << rb) - 1)) == 0 && sub[i] != bst[i >> rb]) ++bad_sub;
+                    for (u32 j = sub[i]; j < sub[i + 1]; ++j) {
+                        if (((k1[j] >> dshift) & dmask) != (i & dmask)) { ++bad_split; if (first_split == ~0u) first_split = j; }
+                        if (j > sub[i] && (k2[j - 1] > k2[j] || (k2[j - 1] == k2[j] && v2[j - 1] >= v2[j]))) { ++bad_sorted; if (first_sorted == ~0u) first_sorted = j; }
+                    }
+                }
+                fprintf(stderr, "[sa_hip] split debug: n=%u rb=%d hb=%d nsub=%u sub[0]=%u sub[last]=%u | table: %llu not monotone, %llu off the bucket starts | split pass: %llu records in the wrong group (first %u) | local pass: %llu out of order (first %u)\n",
+                        n, rb, hb, nsub, sub[0], sub[nsub], (unsigned long long)bad_mono, (unsigned long long)bad_sub, (unsigned long long)bad_split, first_split,
+                        (unsigned long long)bad_sorted, first_sorted);
+            }
+            nw.split_used = true;
+            nw.split_rb = rb;
+            *keys_res = reinterpret_cast<u64*>(keysB);
+            *vals_res = valsB;
+            return 0;
+        }
+    }
+    // histogram of the first narrow digit per bucket
     {
         const u32 tpb = 4;
         const u32 mask0 = (1u << ((np == 1) ? lo_bits : RADIX_BITS)) - 1u;

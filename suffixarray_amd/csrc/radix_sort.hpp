@@ -584,6 +584,7 @@ struct RadixWorkspace {
         SA_HIP_CHECK(hipMalloc(&small, small_bytes()));
         SA_HIP_CHECK(hipMalloc(&dstat, sizeof(DeviceStatus)));
         SA_HIP_CHECK(hipMemset(dstat, 0, sizeof(DeviceStatus)));
+        SA_HIP_CHECK(hipStreamSynchronize(nullptr));   // the fills above run on the null stream, which a non-blocking stream does not wait for
         epoch = 0;
         return timer.init();
     }

@@ -1,0 +1,495 @@
+// radix_split.hpp -- the narrow-record sort in THREE passes over the records instead of five (round 4).
+//
+// radix_narrow.hpp sorts keys of <= 40 bits as: top digit (8 bits, from the text) + four LSD passes over the 32-bit
+// remainder inside the 256 buckets.  Every pass costs ~3.3 ps per record whatever its bytes, so what moves a
+// build is fewer record-passes.  On near-random text -- the only text that takes this plan -- the buckets are even enough
+// for an MSD continuation:
+//
+//   pass              reads              writes                                   bytes / record
+//   top digit         text               u32 narrow key, u32 suffix               1 + 8         (text_top_pass_kernel, unchanged)
+//   histogram         u32 key            hist[bucket][top rb bits of the key]     4             (split_hist_kernel)
+//   split             u32 key, u32 val   the same, grouped by those rb <= 10 bits 8 + 8         (seg_split_kernel)
+//   local finish      u32 key, u32 val   sorted u32 key, u32 suffix (+ int64)     8 + 8 (+ 8)   (local_finish_kernel)
+//
+// After the split pass a SUB-BUCKET -- the records that share the top digit and the next rb key bits, 256 << rb of them --
+// is contiguous and, when the text is as even as the plan assumes, holds at most LOCAL_CAP = 8192 records: one workgroup
+// takes it into LDS whole and orders it completely by the remaining key bits (ties by suffix index, which is what a stable
+// LSD sort from the identity leaves).  D1 at n = 1e9: 137 781 sub-buckets of <= 7 526 + 5 sigma records.
+//
+//   * The split pass need not be stable (the local pass orders by (key, suffix) whatever order it finds), so it ranks
+//     with one returning LDS atomic per record on ONE tile-wide counter array -- no per-wave histograms, which at 1024 bins
+//     would not fit beside the tile.  Geometry, tickets and the per-bucket look-back chains are seg_onesweep_kernel's;
+//     a thread owns two adjacent bins in the count / scan / look-back phases.
+//   * The local pass: bin = the next LOCAL_BIN_BITS = 11 key bits; one returning LDS atomic per record gives its place in the
+//     bin, a scan over the 2048 counters the bin starts; the records go to LDS as u64 (key << 32 | suffix) in bin order, and a
+//     record's final place is its bin's start + the number of records of the bin that compare smaller (a handful: 3.7 on
+//     average at n = 1e9).  A bin with many members only costs time (members^2 comparisons), never correctness.
+//   * Whether the plan applies, and with how many bits rb, is decided on the device's numbers: the histogram is taken over
+//     hb = 10 key bits, split_levels_kernel gives the largest group for every rb <= hb, and the host -- the one
+//     synchronisation this plan adds -- takes the smallest rb whose groups all fit LOCAL_CAP (D1: rb = 3 at n = 4.5e6,
+//     10 at n = 1e9); when none does the sort continues as radix_narrow.hpp's LSD passes (skewed text: the histogram
+//     pass is then the price of finding out).
+//
+// Replaces, by function only, the same libsais stages as radix_sort.hpp; no shared code or structure.
+#pragma once
+
+namespace sa {
+
+constexpr int SPLIT_BITS = 10;
+constexpr int SPLIT_NB = 1 << SPLIT_BITS;       // bins of the split pass (fewer are used when rb < SPLIT_BITS)
+constexpr u32 LOCAL_CAP = 8192;                 // records of a sub-bucket the local pass can hold
+constexpr int LOCAL_BLOCK = 512;
+constexpr int LOCAL_ITEMS = (int)(LOCAL_CAP / LOCAL_BLOCK);
+constexpr int LOCAL_BIN_BITS = 11;
+constexpr int LOCAL_NBINS = 1 << LOCAL_BIN_BITS;
+constexpr int SPLIT_HIST_COPIES = 4;
+
+// histogram of the top rb bits of the narrow keys (digit = (key >> shift) & mask), per bucket: hist[b * SPLIT_NB + d]
+template <int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void split_hist_kernel(const u32* __restrict__ keys, const SegPlan* __restrict__ plan, int shift,
+                                                           u32 mask, u32* __restrict__ hist, u32 tiles_per_block) {
+    constexpr u32 TILE = BLOCK * ITEMS;
+    constexpr int CS = SPLIT_NB + 1;
+    __shared__ u32 s_h[SPLIT_HIST_COPIES * CS];
+    __shared__ u32 s_t[RADIX + 1];
+    for (int i = threadIdx.x; i <= RADIX; i += BLOCK) s_t[i] = plan->tprefix[i];
+    for (int i = threadIdx.x; i < SPLIT_HIST_COPIES * CS; i += BLOCK) s_h[i] = 0;
+    __syncthreads();
+    const u32 F = s_t[RADIX];
+    const u32 f_lo = blockIdx.x * tiles_per_block;
+    const u32 f_hi = (f_lo + tiles_per_block < F) ? f_lo + tiles_per_block : F;
+    if (f_lo >= f_hi) return;
+    u32* my = s_h + (threadIdx.x & (SPLIT_HIST_COPIES - 1)) * CS;
+    auto flush = [&](u32 bucket) {
+        sync_lds();
+        for (int d = threadIdx.x; d < SPLIT_NB; d += BLOCK) {
+            u32 v = 0;
+#pragma unroll
+            for (int k = 0; k < SPLIT_HIST_COPIES; ++k) { v += s_h[k * CS + d]; s_h[k * CS + d] = 0; }
+            if (v) atomicAdd(&hist[bucket * SPLIT_NB + d], v);
+        }
+        sync_lds();
+    };
+    u32 cur = seg_bucket_of(s_t, f_lo);
+    for (u32 f = f_lo; f < f_hi; ++f) {
+        const u32 b = seg_bucket_of(s_t, f);
+        if (b != cur) { flush(cur); cur = b; }
+        const u32 start = plan->bstart[b] + ((f - s_t[b]) * TILE);
+        const u32 end = plan->bstart[b + 1];
+        const u32 len = (end - start) < TILE ? (end - start) : TILE;
+        if (len == TILE) {
+            u32 k[ITEMS];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) k[j] = keys[start + j * BLOCK + threadIdx.x];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) atomicAdd(&my[(k[j] >> shift) & mask], 1u);
+        } else {
+            for (u32 l = threadIdx.x; l < len; l += BLOCK) atomicAdd(&my[(keys[start + l] >> shift) & mask], 1u);
+        }
+    }
+    flush(cur);
+}
+
+// The histogram is taken over hb <= SPLIT_BITS key bits ("fine" bins); grouping the records by only the top k of those bits
+// (level k) merges aligned runs of 2^(hb - k) fine bins.  levels[k] = the largest group at level k over all buckets, k = 0..hb:
+// the host takes the SMALLEST level whose groups all fit the local pass (fewer, fuller sub-buckets and longer runs in the
+// split pass).  One workgroup of SPLIT_NB threads per bucket.
+__global__ __launch_bounds__(SPLIT_NB) void split_levels_kernel(const u32* __restrict__ hist, int hb, u32* __restrict__ levels) {
+    __shared__ u32 s_p[SPLIT_NB + 1];
+    __shared__ u32 s_w[SPLIT_NB / WAVE];
+    const int b = blockIdx.x, d = threadIdx.x, lane = d & 63, w = d >> 6;
+    const u32 c = hist[b * SPLIT_NB + d];
+    u32 incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    for (int i = 0; i < w; ++i) incl += s_w[i];
+    s_p[d + 1] = incl;
+    if (d == 0) s_p[0] = 0;
+    __syncthreads();
+    for (int k = 0; k <= hb; ++k) {
+        const int g = hb - k;   // log2 of the fine bins per group
+        u32 v = 0;
+        if (d < (1 << k)) v = s_p[(d + 1) << g] - s_p[d << g];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const u32 t = __shfl_down(v, o); v = t > v ? t : v; }
+        if (lane == 0 && v) atomicMax(&levels[k], v);
+    }
+}
+
+// For the level rb the host has chosen: base[b * SPLIT_NB + D] = bstart[b] + the records of bucket b whose top rb key bits are
+// below D (the split pass's digit bases; D < 2^rb, the other entries 0), and the compact table of sub-bucket starts
+// sub[(b << rb) + D] (sub[256 << rb] = n).
+__global__ __launch_bounds__(SPLIT_NB) void split_scan_kernel(const u32* __restrict__ hist, const SegPlan* __restrict__ plan, int hb, int rb,
+                                                              u32* __restrict__ base, u32* __restrict__ sub) {
+    __shared__ u32 s_w[SPLIT_NB / WAVE];
+    const int b = blockIdx.x, d = threadIdx.x, lane = d & 63, w = d >> 6;
+    const u32 c = hist[b * SPLIT_NB + d];
+    u32 incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    u32 run = plan->bstart[b] + incl - c;
+    for (int i = 0; i < w; ++i) run += s_w[i];
+    const int g = hb - rb;
+    u32 out = 0;
+    if (d < (1 << hb) && (d & ((1 << g) - 1)) == 0) {
+        out = run;
+        sub[((u32)b << rb) + (u32)(d >> g)] = run;
+    }
+    // the split pass reads base[b][D] for D < SPLIT_NB: entry D = the start of group D
+    __shared__ u32 s_o[SPLIT_NB];
+    s_o[d] = 0;
+    __syncthreads();
+    if (d < (1 << hb) && (d & ((1 << g) - 1)) == 0) s_o[d >> g] = out;
+    __syncthreads();
+    base[b * SPLIT_NB + d] = s_o[d];
+    if (d == 0 && b == RADIX - 1) sub[(u32)RADIX << rb] = plan->bstart[RADIX];
+}
+
+// decoupled look-back for the two adjacent bins a thread owns (status rows of SPLIT_NB granules); radix_sort.hpp's
+// lookback_prefix with both chains advanced in the same window loads
+template <int LB_WINDOW = SA_LB_WINDOW>
+__device__ __forceinline__ void lookback_prefix_pair(const u64* __restrict__ status, u32 tile, u32 first_tile, u32 digit0,
+                                                     u32 epoch, DeviceStatus* dstat, u32& p0, u32& p1) {
+    u32 pre[2] = {0u, 0u};
+    bool done[2] = {false, false};
+    int64_t t = (int64_t)tile - 1;
+    const int64_t t0 = (int64_t)first_tile;
+    while (t >= t0 && !(done[0] && done[1])) {
+        u64 w[LB_WINDOW][2];
+#pragma unroll
+        for (int i = 0; i < LB_WINDOW; ++i) {
+            const int64_t ti = t - i;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                w[i][k] = (ti >= t0 && !done[k])
+                              ? __hip_atomic_load(&status[(u64)ti * SPLIT_NB + digit0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                              : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int i = 0; i < LB_WINDOW; ++i) {
+                const int64_t ti = t - i;
+                if (!done[k] && ti >= t0) {
+                    u64 x = w[i][k];
+                    u32 spins = 0;
+                    while (!((u32)(x >> 34) == epoch && ((x >> 32) & 3u) != 0)) {
+                        ++spins;
+                        if ((spins & 1023u) == 0) {
+                            if (spins >= SPIN_LIMIT ||
+                                __hip_atomic_load(&dstat->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                                __hip_atomic_store(&dstat->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                p0 = pre[0]; p1 = pre[1];
+                                return;   // poisoned; the host reports SA_HIP_EINTERNAL
+                            }
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                        x = __hip_atomic_load(&status[(u64)ti * SPLIT_NB + digit0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    pre[k] += (u32)x;
+                    if (((x >> 32) & 3u) == FLAG_INCL) done[k] = true;
+                }
+            }
+        }
+        t -= LB_WINDOW;
+    }
+    p0 = pre[0]; p1 = pre[1];
+}
+
+struct SplitPassArgs {
+    const u32* keys_in;
+    const u32* vals_in;
+    u32* keys_out;
+    u32* vals_out;
+    const SegPlan* plan;
+    int shift;             // digit = (key >> shift) & mask: the top rb bits of the narrow key
+    u32 mask;
+    const u32* digit_base; // [RADIX buckets][SPLIT_NB]
+    u64* status;           // [flat tiles][SPLIT_NB]
+    u32* ticket;           // [NCHUNK] (zeroed by the host)
+    u32 epoch;
+    DeviceStatus* dstat;
+    u32 incl_mask;
+};
+
+template <bool FULL, int BLOCK, int ITEMS>
+__device__ __forceinline__ void split_tile(const SplitPassArgs& a, const u32 flat, const u32 first_flat, const u32 bucket,
+                                           const u32 start, const u32 tile_n, u32* s_keys, u32* s_cnt, u32* s_gdelta, u32* s_wsum) {
+    static_assert(SPLIT_NB == 2 * BLOCK, "two bins per thread");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 woff = (u32)wave * (WAVE * ITEMS) + lane;
+
+    // the bases of this thread's two bins: requested now, needed after the look-back
+    const uint2 dbase = *reinterpret_cast<const uint2*>(a.digit_base + (size_t)bucket * SPLIT_NB + 2 * tid);
+
+    // 1. load (wave-striped), 2. place inside the tile's bin from one returning LDS atomic per record (any order will do)
+    u32 key[ITEMS];
+    const u32* kin = a.keys_in + start;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 p = woff + j * WAVE;
+        key[j] = (FULL || p < tile_n) ? kin[p] : 0u;
+    }
+    // (branch-free: a slot beyond the tile counts into the spare word s_cnt[SPLIT_NB] -- an atomic under a per-record branch made
+    //  the compiler keep pos[] as one 32-wide vector value and spill it at every branch: 7 288 spilled registers)
+    u32 pos[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 d = (key[j] >> a.shift) & a.mask;
+        pos[j] = atomicAdd(&s_cnt[(FULL || (woff + j * WAVE) < tile_n) ? d : (u32)SPLIT_NB], 1u);
+    }
+    sync_lds();
+
+    // 3. bin counts -> aggregate published -> exclusive scan over the bins
+    const uint2 c = *reinterpret_cast<const uint2*>(s_cnt + 2 * tid);
+    {
+        const u64 fl = (flat == first_flat) ? FLAG_INCL : FLAG_AGG;
+        __hip_atomic_store(&a.status[(u64)flat * SPLIT_NB + 2 * tid], pack_status(a.epoch, fl, c.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.status[(u64)flat * SPLIT_NB + 2 * tid + 1], pack_status(a.epoch, fl, c.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const u32 tot = c.x + c.y;
+    u32 incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();   // (every thread has read its two counters)
+    u32 excl = incl - tot;
+    for (int i = 0; i < wave; ++i) excl += s_wsum[i];
+    *reinterpret_cast<uint2*>(s_cnt + 2 * tid) = make_uint2(excl, excl + c.x);   // the bins' tile-local starts
+    __syncthreads();
+
+    // 4. keys -> LDS at their tile-local position
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        pos[j] += s_cnt[(key[j] >> a.shift) & a.mask];
+        if (FULL || (woff + j * WAVE) < tile_n) s_keys[pos[j]] = key[j];
+    }
+    __syncthreads();
+
+    // 5. look-back inside the bucket, both bins of the thread at once
+    {
+        u32 p0 = 0, p1 = 0;
+        if (flat > first_flat) {
+            lookback_prefix_pair(a.status, flat, first_flat, 2u * (u32)tid, a.epoch, a.dstat, p0, p1);
+            if (((flat - first_flat) & a.incl_mask) == a.incl_mask) {
+                __hip_atomic_store(&a.status[(u64)flat * SPLIT_NB + 2 * tid], pack_status(a.epoch, FLAG_INCL, p0 + c.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.status[(u64)flat * SPLIT_NB + 2 * tid + 1], pack_status(a.epoch, FLAG_INCL, p1 + c.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        *reinterpret_cast<uint2*>(s_gdelta + 2 * tid) = make_uint2(dbase.x + p0 - excl, dbase.y + p1 - (excl + c.x));
+    }
+    __syncthreads();
+
+    // 6. coalesced stores per bin run: keys, then the values through the same LDS
+    u32 gidx[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const u32 p = k * BLOCK + tid;
+        if (FULL || p < tile_n) {
+            const u32 kk = s_keys[p];
+            gidx[k] = s_gdelta[(kk >> a.shift) & a.mask] + p;
+            a.keys_out[gidx[k]] = kk;
+        }
+    }
+    u32 val[ITEMS];
+    const u32* vin = a.vals_in + start;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 p = woff + j * WAVE;
+        val[j] = (FULL || p < tile_n) ? vin[p] : 0u;
+    }
+    __syncthreads();   // every read of s_keys is done
+    u32* s_vals = s_keys;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+        if (FULL || (woff + j * WAVE) < tile_n) s_vals[pos[j]] = val[j];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const u32 p = k * BLOCK + tid;
+        if (FULL || p < tile_n) a.vals_out[gidx[k]] = s_vals[p];
+    }
+}
+
+template <int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK, 4) void seg_split_kernel(SplitPassArgs a) {
+    constexpr u32 TILE = BLOCK * ITEMS;
+    __shared__ __attribute__((aligned(16))) u32 s_keys[TILE];   // reused for the values
+    __shared__ __attribute__((aligned(16))) u32 s_cnt[SPLIT_NB + 4];   // [SPLIT_NB]: spare word for slots beyond a partial tile
+    __shared__ __attribute__((aligned(16))) u32 s_gdelta[SPLIT_NB];
+    __shared__ u32 s_wsum[BLOCK / WAVE];
+    __shared__ u32 s_t[RADIX + 1];
+    __shared__ u32 s_b[RADIX + 1];
+    __shared__ u32 s_c[NCHUNK + 1];
+    __shared__ u32 s_flat;
+
+    const int tid = threadIdx.x;
+    u32 home = 0, t_home = 0;
+    if (tid == 0) {
+        home = xcc_id();
+        t_home = atomicAdd(&a.ticket[home], 1u);
+    }
+    for (int i = tid; i <= RADIX; i += BLOCK) { s_t[i] = a.plan->tprefix[i]; s_b[i] = a.plan->bstart[i]; }
+    if (tid <= NCHUNK) s_c[tid] = a.plan->cfirst[tid];
+    for (int i = tid; i < SPLIT_NB + 4; i += BLOCK) s_cnt[i] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        u32 flat = 0xFFFFFFFFu;
+        if (t_home < s_c[home + 1] - s_c[home]) flat = s_c[home] + t_home;
+        for (int k = 1; k < NCHUNK && flat == 0xFFFFFFFFu; ++k) {   // own part exhausted: steal
+            const u32 c = (home + k) & (NCHUNK - 1);
+            const u32 cnt = s_c[c + 1] - s_c[c];
+            if (cnt == 0) continue;
+            const u32 t = atomicAdd(&a.ticket[c], 1u);
+            if (t < cnt) flat = s_c[c] + t;
+        }
+        s_flat = flat;
+    }
+    __syncthreads();
+    const u32 flat = s_flat;
+    if (flat == 0xFFFFFFFFu) return;   // block-uniform
+    const u32 bucket = seg_bucket_of(s_t, flat);
+    const u32 first_flat = s_t[bucket];
+    const u32 start = s_b[bucket] + (flat - first_flat) * TILE;
+    const u32 rest = s_b[bucket + 1] - start;
+    if (rest >= TILE) split_tile<true, BLOCK, ITEMS>(a, flat, first_flat, bucket, start, TILE, s_keys, s_cnt, s_gdelta, s_wsum);
+    else split_tile<false, BLOCK, ITEMS>(a, flat, first_flat, bucket, start, rest, s_keys, s_cnt, s_gdelta, s_wsum);
+}
+
+// ---- local finish: one sub-bucket per workgroup, ordered completely in LDS ------------------------------------------------
+struct LocalArgs {
+    const u32* keys_in;
+    const u32* vals_in;
+    u32* keys_out;
+    u32* vals_out;
+    int64_t* vals_out64;   // may be null: the suffixes also leave as int64 (libsais64 layout, as seg_onesweep_kernel's LAST form)
+    const u32* sub;        // [nsub + 1] starts of the sub-buckets
+    int bin_shift;         // bin = (key >> bin_shift) & bin_mask: the key bits right below the sub-bucket's
+    u32 bin_mask;
+    DeviceStatus* dstat;
+};
+
+__global__ __launch_bounds__(LOCAL_BLOCK, 4) void local_finish_kernel(LocalArgs a) {
+    constexpr int BLOCK = LOCAL_BLOCK, ITEMS = LOCAL_ITEMS;
+    static_assert(LOCAL_NBINS == 4 * BLOCK, "four bins per thread in the scan");
+    __shared__ __attribute__((aligned(16))) u64 s_rec[LOCAL_CAP];
+    __shared__ __attribute__((aligned(16))) u32 s_bin[LOCAL_NBINS + 4];
+    __shared__ u32 s_wsum[BLOCK / WAVE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 s = a.sub[blockIdx.x];
+    const u32 m = a.sub[blockIdx.x + 1] - s;
+    if (m == 0) return;
+    if (m > LOCAL_CAP) {   // cannot happen: the host has seen the largest sub-bucket
+        if (tid == 0) __hip_atomic_store(&a.dstat->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const u32* kin = a.keys_in + s;
+    const u32* vin = a.vals_in + s;
+    if (m == 1) {
+        if (tid == 0) {
+            const u32 k = kin[0], v = vin[0];
+            a.keys_out[s] = k; a.vals_out[s] = v;
+            if (a.vals_out64) a.vals_out64[s] = (int64_t)v;
+        }
+        return;
+    }
+    *reinterpret_cast<uint4*>(s_bin + 4 * tid) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    // 1. load; place inside the bin from one returning LDS atomic per record
+    u32 key[ITEMS], val[ITEMS], r[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 p = (u32)j * BLOCK + tid;
+        key[j] = 0; val[j] = 0;
+        if ((u32)j * BLOCK < m && p < m) { key[j] = kin[p]; val[j] = vin[p]; }
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 p = (u32)j * BLOCK + tid;
+        r[j] = 0;
+        if ((u32)j * BLOCK < m && p < m) r[j] = atomicAdd(&s_bin[(key[j] >> a.bin_shift) & a.bin_mask], 1u);
+    }
+    sync_lds();
+
+    // 2. bin counts -> bin starts
+    {
+        const uint4 c = *reinterpret_cast<const uint4*>(s_bin + 4 * tid);
+        const u32 tot = c.x + c.y + c.z + c.w;
+        u32 incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        u32 excl = incl - tot;
+        for (int i = 0; i < wave; ++i) excl += s_wsum[i];
+        *reinterpret_cast<uint4*>(s_bin + 4 * tid) = make_uint4(excl, excl + c.x, excl + c.x + c.y, excl + c.x + c.y + c.z);
+        if (tid == BLOCK - 1) s_bin[LOCAL_NBINS] = m;
+    }
+    __syncthreads();
+
+    // 3. records -> LDS in bin order
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 p = (u32)j * BLOCK + tid;
+        if ((u32)j * BLOCK < m && p < m) {
+            const u32 slot = s_bin[(key[j] >> a.bin_shift) & a.bin_mask] + r[j];
+            s_rec[slot] = ((u64)key[j] << 32) | (u64)val[j];
+        }
+    }
+    __syncthreads();
+
+    // 4. final place of slot p: its bin's start + the records of the bin that compare smaller (key, then suffix)
+    u64 rec[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 p = (u32)j * BLOCK + tid;
+        rec[j] = 0; r[j] = 0;
+        if ((u32)j * BLOCK < m && p < m) {
+            const u64 x = s_rec[p];
+            const u32 bin = ((u32)(x >> 32) >> a.bin_shift) & a.bin_mask;
+            const u32 lo = s_bin[bin], hi = s_bin[bin + 1];
+            u32 cnt = 0;
+            for (u32 q = lo; q < hi; ++q) cnt += (s_rec[q] < x) ? 1u : 0u;
+            rec[j] = x;
+            r[j] = lo + cnt;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 p = (u32)j * BLOCK + tid;
+        if ((u32)j * BLOCK < m && p < m) s_rec[r[j]] = rec[j];
+    }
+    __syncthreads();
+
+    // 5. out, coalesced
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 p = (u32)j * BLOCK + tid;
+        if ((u32)j * BLOCK < m && p < m) {
+            const u64 x = s_rec[p];
+            a.keys_out[s + p] = (u32)(x >> 32);
+            a.vals_out[s + p] = (u32)x;
+            if (a.vals_out64) a.vals_out64[s + p] = (int64_t)(u32)x;
+        }
+    }
+}
+
+}  // namespace sa

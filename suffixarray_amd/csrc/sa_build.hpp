@@ -1963,6 +1963,8 @@ struct Builder {
             if ((rc = radix_sort_narrow(radix, narrow, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(),
                                         n32, begin_bit, &kres, &vres, text_pass ? &src : nullptr, keep_narrow, sa64_out))) return rc;
             if (sa64_out) stats.widen_fused = 1;
+            stats.split_plan = narrow.split_used ? (u32)narrow.split_rb : 0u;
+            stats.split_max = narrow.split_max_seen;
         } else if (narrow48_path) {
             // The 56 key bits hold k0 whole characters and, when the next one does not fit, its TOP bits: the key is the first
             // 56 bits of the (k0 + 1)-character key.  Groups are still classes of the first k0 characters (h = k0) cut a little

@@ -156,6 +156,78 @@ def test_narrow_record_sort_matches_plain_sort(gpu, oracle, monkeypatch):
         assert np.array_equal(idx.sa_u32(), oracle.sais(t).astype(np.uint32))
 
 
+def test_split_plan_matches_lsd_passes(gpu, oracle, monkeypatch):
+    """The three-pass plan of the narrow sort (radix_split.hpp: top digit, split pass by the next rb key bits, every sub-bucket
+    ordered completely in LDS) against the five-pass plan (SA_HIP_SPLIT=0: LSD passes inside the buckets): the same suffix
+    array bit for bit, verified on the device, the oracle's on two texts.  Uniform text at several sizes and forced key
+    lengths (levels rb = 1..8 by lowering the bound on a sub-bucket), DNA-like text, truncated builds whose ties must stay
+    in text order (k0 = L), the fused int64 copy; skewed and word text must DECLINE the plan (a sub-bucket beyond the bound)
+    and still come out right."""
+    from suffixarray_amd import synth
+    rng = np.random.default_rng(14)
+    dna = rng.choice(np.frombuffer(b"acgt", np.uint8), 5_000_000)
+    skew = rng.choice(np.array([97, 98, 99, 100, 122], dtype=np.uint8), 6_000_000, p=[0.9, 0.04, 0.03, 0.02, 0.01])
+    d1 = synth.d1_uniform27(6_000_000)
+    runs = [("d1", synth.d1_uniform27(4_500_001), 0, 0, 0, True), ("d1_k7", d1, 7, 0, 0, True), ("d1_L8", synth.d1_uniform27(5_000_000), 0, 8, 0, True),
+            ("d1_cap2048", d1, 0, 0, 2048, True), ("d1_cap300", d1, 0, 0, 300, True), ("d1_k6_cap1000", d1, 6, 0, 1000, True),
+            ("dna_k13", dna, 13, 0, 0, True), ("d1_L8_cap500", synth.d1_uniform27(5_000_000), 0, 8, 500, True),
+            ("skew", skew, 13, 0, 0, False), ("words_k8", synth.d2_words(8_000_000), 8, 0, 0, None)]
+    levels = set()
+    failures = []
+    for name, t, k0, L, cap, taken in runs:
+        if k0:
+            monkeypatch.setenv("SA_HIP_INITIAL_CHARS", str(k0))
+        else:
+            monkeypatch.delenv("SA_HIP_INITIAL_CHARS", raising=False)
+        if cap:
+            monkeypatch.setenv("SA_HIP_SPLIT_CAP", str(cap))
+        else:
+            monkeypatch.delenv("SA_HIP_SPLIT_CAP", raising=False)
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SA_HIP_SPLIT", mode)
+            with gpu.DeviceIndex(t.size, 0) as idx:
+                try:
+                    idx.build(t, L)
+                except Exception as e:
+                    failures.append((name, mode, str(e), {k: v for k, v in idx.build_stats().items() if k.startswith("split") or k == "initial_chars"}))
+                    got[mode] = None
+                    continue
+                st = idx.build_stats()
+                assert st["narrow_k"] == 1, (name, st)
+                if mode == "0":
+                    assert st["split_plan"] == 0 and st["split_max"] == 0, (name, st)
+                else:
+                    assert st["split_max"] > 0 and (st["split_plan"] > 0) == (st["split_max"] <= (cap or 8192)), (name, st)
+                    assert taken is None or (st["split_plan"] > 0) == taken, (name, st)
+                    levels.add(st["split_plan"])
+                assert idx.verify() == 0, (name, st)
+                got[mode] = idx.sa_u32().copy()
+        if got["1"] is None or got["0"] is None:
+            continue
+        assert np.array_equal(got["1"], got["0"]), name
+        if name in ("d1", "d1_L8_cap500"):
+            ref = oracle.sais(t).astype(np.uint32) if L == 0 else oracle.truncated_sa(t, L).astype(np.uint32)
+            assert np.array_equal(got["1"], ref), name
+    assert not failures, failures
+    assert len(levels - {0}) >= 3, levels
+    # the int64 copy leaves the local pass with the suffixes
+    monkeypatch.delenv("SA_HIP_INITIAL_CHARS", raising=False)
+    monkeypatch.delenv("SA_HIP_SPLIT_CAP", raising=False)
+    monkeypatch.setenv("SA_HIP_SPLIT", "1")
+    import torch
+    t = runs[0][1]
+    with gpu.DeviceIndex(t.size, 0) as idx:
+        idx.build(t)
+        out = torch.full((t.size,), -7, dtype=torch.int64, device="cuda:0")
+        torch.cuda.synchronize()
+        idx.build_device64(idx.text_dev, t.size, out.data_ptr(), 0)
+        idx.sync()
+        st = idx.build_stats()
+        assert st["split_plan"] > 0 and st["widen_fused"] == 1, st
+        assert np.array_equal(out.cpu().numpy(), oracle.sais(t).astype(np.int64))
+
+
 def test_narrow48_record_sort_matches_wide_sort(gpu, oracle, monkeypatch):
     """Initial keys of 41..56 bits are sorted as 10-byte records (radix_narrow48.hpp: top digit from the text, the 48-bit
     remainder as u32 + u16, two passes ranked by the u16 part, three or four by the u32 part, u64 keys rebuilt by the last
