@@ -948,6 +948,8 @@ struct NarrowWorkspace {
     u32* split_levels_dev() const { return split_sub + split_sub_words(); }   // [16]: largest group per level
     u32 split_cap = LOCAL_CAP;     // SA_HIP_SPLIT_CAP (tests: a smaller bound makes small texts take more levels)
     int split_rb = 0;              // level of the last sort that took the plan
+    int local_bin_bits = 12;       // SA_HIP_LOCAL_BINS=11: 2048 bins in the local pass
+    int split_items = 28;          // SA_HIP_SPLIT_ITEMS=24 / 28 / 32: tiles of 12288 / 14336 / 16384 records in the split pass (32 spills 33 registers)
     static size_t hist_bytes() { return (size_t)NARROW_MAX_PASSES * RADIX * RADIX * sizeof(u32); }
     int init() {
         SA_HIP_CHECK(hipMalloc(&plan, sizeof(SegPlan)));
@@ -960,6 +962,8 @@ struct NarrowWorkspace {
         SA_HIP_CHECK(hipMalloc(&split_sub, (split_sub_words() + 16) * sizeof(u32)));
         SA_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host_word), 64, hipHostMallocDefault));
         if (const char* e = diag_env("SA_HIP_SPLIT")) split_enabled = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_LOCAL_BINS")) local_bin_bits = (atoi(e) == 11) ? 11 : 12;
+        if (const char* e = diag_env("SA_HIP_SPLIT_ITEMS")) { const int v = atoi(e); split_items = (v == 24 || v == 28) ? v : 32; }
         if (const char* e = diag_env("SA_HIP_SPLIT_CAP")) { const int v = atoi(e); if (v >= 64 && v <= (int)LOCAL_CAP) split_cap = (u32)v; }
         return 0;
     }
@@ -1106,20 +1110,30 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
         }
     }
     const u32 seg_tile_n = 512u * SEG_ITEMS;
-    hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(256), 0, stream, ws.hist(0), seg_tile_n, nw.plan);
     const u32 flat_max = n / seg_tile_n + 1 + RADIX;   // >= sum over buckets of ceil(size / tile)
+    const bool try_split = nw.split_enabled && keep_narrow && ws.block == 512 && lo_bits - LOCAL_BIN_BITS >= 1;
+    const u32 split_tile_n = 512u * (u32)nw.split_items;   // the split pass has its own tile size: the plan is made for it first
+    const u32 split_flat_max = n / split_tile_n + 1 + RADIX;
+    hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(256), 0, stream, ws.hist(0), try_split ? split_tile_n : seg_tile_n, nw.plan);
     // narrow keys now in keysB (u32), values in valsB.
     // Three-pass plan (radix_split.hpp): the records of a bucket are grouped by their next rb key bits, then every group is
     // ordered completely in LDS -- when the largest group fits (near-random text; the device's own count decides)
     nw.split_used = false;
     nw.split_max_seen = 0;
-    if (nw.split_enabled && keep_narrow && ws.block == 512 && lo_bits - LOCAL_BIN_BITS >= 1) {
+    if (try_split) {
         const int hb = (lo_bits - LOCAL_BIN_BITS < SPLIT_BITS) ? lo_bits - LOCAL_BIN_BITS : SPLIT_BITS;   // key bits the histogram looks at
         SA_HIP_CHECK(hipMemsetAsync(nw.split_hist, 0, NarrowWorkspace::split_table_bytes(), stream));
         SA_HIP_CHECK(hipMemsetAsync(nw.split_levels_dev(), 0, 16 * sizeof(u32), stream));
         const u32 tpb = 4;
-        hipLaunchKernelGGL((split_hist_kernel<512, SEG_ITEMS>), dim3(div_up(flat_max, tpb)), dim3(512), 0, stream,
-                           reinterpret_cast<const u32*>(keysB), nw.plan, lo_bits - hb, (1u << hb) - 1u, nw.split_hist, tpb);
+        if (nw.split_items == 32)
+            hipLaunchKernelGGL((split_hist_kernel<512, 32>), dim3(div_up(split_flat_max, tpb)), dim3(512), 0, stream,
+                               reinterpret_cast<const u32*>(keysB), nw.plan, lo_bits - hb, (1u << hb) - 1u, nw.split_hist, tpb);
+        else if (nw.split_items == 28)
+            hipLaunchKernelGGL((split_hist_kernel<512, 28>), dim3(div_up(split_flat_max, tpb)), dim3(512), 0, stream,
+                               reinterpret_cast<const u32*>(keysB), nw.plan, lo_bits - hb, (1u << hb) - 1u, nw.split_hist, tpb);
+        else
+            hipLaunchKernelGGL((split_hist_kernel<512, 24>), dim3(div_up(split_flat_max, tpb)), dim3(512), 0, stream,
+                               reinterpret_cast<const u32*>(keysB), nw.plan, lo_bits - hb, (1u << hb) - 1u, nw.split_hist, tpb);
         hipLaunchKernelGGL(split_levels_kernel, dim3(RADIX), dim3(SPLIT_NB), 0, stream, (const u32*)nw.split_hist, hb, nw.split_levels_dev());
         SA_HIP_CHECK(hipMemcpyAsync(nw.host_word, nw.split_levels_dev(), 16 * sizeof(u32), hipMemcpyDeviceToHost, stream));
         SA_HIP_CHECK(hipStreamSynchronize(stream));
@@ -1133,7 +1147,7 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
             const u32 dmask = (1u << rb) - 1u;
             hipLaunchKernelGGL(split_scan_kernel, dim3(RADIX), dim3(SPLIT_NB), 0, stream, (const u32*)nw.split_hist, nw.plan, hb, rb,
                                nw.split_base, nw.split_sub);
-            if ((rc = nw.ensure_split_status(flat_max, stream))) return rc;
+            if ((rc = nw.ensure_split_status(split_flat_max, stream))) return rc;
             if (++ws.epoch >= (1u << 30)) {
                 SA_HIP_CHECK(hipMemsetAsync(ws.status, 0, (size_t)ws.max_tiles * RADIX * sizeof(u64), stream));
                 ws.epoch = 1;
@@ -1147,18 +1161,22 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
             a.plan = nw.plan; a.shift = dshift; a.mask = dmask; a.digit_base = nw.split_base; a.status = nw.split_status;
             a.ticket = nw.tickets; a.epoch = ws.epoch; a.dstat = ws.dstat; a.incl_mask = SA_INCL_MASK;
             if ((rc = ws.timer.start(stream, 2))) return rc;
-            hipLaunchKernelGGL((seg_split_kernel<512, SEG_ITEMS>), dim3(flat_max), dim3(512), 0, stream, a);
+            if (nw.split_items == 32) hipLaunchKernelGGL((seg_split_kernel<512, 32>), dim3(split_flat_max), dim3(512), 0, stream, a);
+            else if (nw.split_items == 28) hipLaunchKernelGGL((seg_split_kernel<512, 28>), dim3(split_flat_max), dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((seg_split_kernel<512, 24>), dim3(split_flat_max), dim3(512), 0, stream, a);
             if ((rc = ws.timer.stop(stream, (u64)n * 16u))) return rc;
             ws.pass_records += n; ws.pass_bytes += (u64)n * 16u; ws.passes += 1;
             LocalArgs l;
             l.keys_in = reinterpret_cast<const u32*>(keysA); l.vals_in = valsA;
             l.keys_out = reinterpret_cast<u32*>(keysB); l.vals_out = valsB; l.vals_out64 = vals_res64;
             l.sub = nw.split_sub;
-            l.bin_shift = rest_bits - LOCAL_BIN_BITS; l.bin_mask = (u32)LOCAL_NBINS - 1u;
+            const int bb = (rest_bits >= 12 && nw.local_bin_bits == 12) ? 12 : 11;
+            l.bin_shift = rest_bits - bb;
             l.dstat = ws.dstat;
             const u64 local_bytes = (u64)n * 16u + (vals_res64 ? (u64)n * 8u : 0u);
             if ((rc = ws.timer.start(stream, 3))) return rc;
-            hipLaunchKernelGGL(local_finish_kernel, dim3((u32)RADIX << rb), dim3(LOCAL_BLOCK), 0, stream, l);
+            if (bb == 12) hipLaunchKernelGGL(local_finish_kernel<12>, dim3((u32)RADIX << rb), dim3(LOCAL_BLOCK), 0, stream, l);
+            else hipLaunchKernelGGL(local_finish_kernel<11>, dim3((u32)RADIX << rb), dim3(LOCAL_BLOCK), 0, stream, l);
             if ((rc = ws.timer.stop(stream, local_bytes))) return rc;
             ws.pass_records += n; ws.pass_bytes += local_bytes; ws.passes += 1;
             SA_HIP_CHECK(hipGetLastError());
@@ -1192,6 +1210,8 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
             return 0;
         }
     }
+    if (try_split && split_tile_n != seg_tile_n)   // declined: the plan again, for the tiles of the LSD passes
+        hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(256), 0, stream, ws.hist(0), seg_tile_n, nw.plan);
     // histogram of the first narrow digit per bucket
     {
         const u32 tpb = 4;

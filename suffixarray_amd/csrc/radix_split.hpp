@@ -40,8 +40,7 @@ constexpr int SPLIT_NB = 1 << SPLIT_BITS;       // bins of the split pass (fewer
 constexpr u32 LOCAL_CAP = 8192;                 // records of a sub-bucket the local pass can hold
 constexpr int LOCAL_BLOCK = 512;
 constexpr int LOCAL_ITEMS = (int)(LOCAL_CAP / LOCAL_BLOCK);
-constexpr int LOCAL_BIN_BITS = 11;
-constexpr int LOCAL_NBINS = 1 << LOCAL_BIN_BITS;
+constexpr int LOCAL_BIN_BITS = 11;            // the key bits below a sub-bucket's that the plan asks for at least (bins of the local pass: 11 or 12 bits)
 constexpr int SPLIT_HIST_COPIES = 4;
 
 // histogram of the top rb bits of the narrow keys (digit = (key >> shift) & mask), per bucket: hist[b * SPLIT_NB + d]
@@ -294,6 +293,11 @@ __device__ __forceinline__ void split_tile(const SplitPassArgs& a, const u32 fla
     __syncthreads();
 
     // 6. coalesced stores per bin run: keys, then the values through the same LDS
+    //    (the tile-local positions wait packed two per register: with 32 records per thread the kernel would spill otherwise)
+    static_assert(ITEMS % 2 == 0 && BLOCK * ITEMS <= 65536, "positions packed as 16-bit pairs");
+    u32 pp[ITEMS / 2];
+#pragma unroll
+    for (int j = 0; j < ITEMS / 2; ++j) pp[j] = pos[2 * j] | (pos[2 * j + 1] << 16);
     u32 gidx[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
@@ -315,7 +319,7 @@ __device__ __forceinline__ void split_tile(const SplitPassArgs& a, const u32 fla
     u32* s_vals = s_keys;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j)
-        if (FULL || (woff + j * WAVE) < tile_n) s_vals[pos[j]] = val[j];
+        if (FULL || (woff + j * WAVE) < tile_n) s_vals[(pp[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu] = val[j];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
@@ -377,16 +381,21 @@ struct LocalArgs {
     u32* vals_out;
     int64_t* vals_out64;   // may be null: the suffixes also leave as int64 (libsais64 layout, as seg_onesweep_kernel's LAST form)
     const u32* sub;        // [nsub + 1] starts of the sub-buckets
-    int bin_shift;         // bin = (key >> bin_shift) & bin_mask: the key bits right below the sub-bucket's
-    u32 bin_mask;
+    int bin_shift;         // bin = (key >> bin_shift) & (2^BB - 1): the key bits right below the sub-bucket's
     DeviceStatus* dstat;
 };
 
+// BB: bin bits (11 or 12).  The counters are 16 bits wide, two per LDS word (a sub-bucket holds <= 8192 records), so that
+// 4096 bins cost the 8 KB that 2048 32-bit counters did: 1.8 instead of 3.7 records per bin at n = 1e9, and it is the
+// LARGEST bin among a wave's 64 records that sets the trip count of the counting loop.
+template <int BB>
 __global__ __launch_bounds__(LOCAL_BLOCK, 4) void local_finish_kernel(LocalArgs a) {
     constexpr int BLOCK = LOCAL_BLOCK, ITEMS = LOCAL_ITEMS;
-    static_assert(LOCAL_NBINS == 4 * BLOCK, "four bins per thread in the scan");
-    __shared__ __attribute__((aligned(16))) u64 s_rec[LOCAL_CAP];
-    __shared__ __attribute__((aligned(16))) u32 s_bin[LOCAL_NBINS + 4];
+    constexpr int NB = 1 << BB, WORDS = NB / 2, WPT = WORDS / BLOCK;   // packed counter words, words per thread in the scan
+    static_assert(WPT >= 1 && WPT * BLOCK == WORDS, "the scan covers the counters exactly");
+    static_assert(LOCAL_CAP < 65536, "16-bit counters and starts");
+    __shared__ __attribute__((aligned(16))) u64 s_rec[LOCAL_CAP + 2];
+    __shared__ __attribute__((aligned(16))) u32 s_cw[WORDS + 4];   // counts, then starts, of bins 2w | 2w + 1 << 16; [WORDS] low half: start[NB] = m
     __shared__ u32 s_wsum[BLOCK / WAVE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 s = a.sub[blockIdx.x];
@@ -406,7 +415,8 @@ __global__ __launch_bounds__(LOCAL_BLOCK, 4) void local_finish_kernel(LocalArgs 
         }
         return;
     }
-    *reinterpret_cast<uint4*>(s_bin + 4 * tid) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) s_cw[WPT * tid + i] = 0;
     __syncthreads();
 
     // 1. load; place inside the bin from one returning LDS atomic per record
@@ -421,14 +431,20 @@ __global__ __launch_bounds__(LOCAL_BLOCK, 4) void local_finish_kernel(LocalArgs 
     for (int j = 0; j < ITEMS; ++j) {
         const u32 p = (u32)j * BLOCK + tid;
         r[j] = 0;
-        if ((u32)j * BLOCK < m && p < m) r[j] = atomicAdd(&s_bin[(key[j] >> a.bin_shift) & a.bin_mask], 1u);
+        if ((u32)j * BLOCK < m && p < m) {
+            const u32 b = (key[j] >> a.bin_shift) & (u32)(NB - 1);
+            const u32 sh = (b & 1u) * 16u;
+            r[j] = (atomicAdd(&s_cw[b >> 1], 1u << sh) >> sh) & 0xFFFFu;
+        }
     }
     sync_lds();
 
     // 2. bin counts -> bin starts
     {
-        const uint4 c = *reinterpret_cast<const uint4*>(s_bin + 4 * tid);
-        const u32 tot = c.x + c.y + c.z + c.w;
+        u32 cw[WPT];
+        u32 tot = 0;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) { cw[i] = s_cw[WPT * tid + i]; tot += (cw[i] & 0xFFFFu) + (cw[i] >> 16); }
         u32 incl = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -437,25 +453,32 @@ __global__ __launch_bounds__(LOCAL_BLOCK, 4) void local_finish_kernel(LocalArgs 
         }
         if (lane == 63) s_wsum[wave] = incl;
         __syncthreads();
-        u32 excl = incl - tot;
-        for (int i = 0; i < wave; ++i) excl += s_wsum[i];
-        *reinterpret_cast<uint4*>(s_bin + 4 * tid) = make_uint4(excl, excl + c.x, excl + c.x + c.y, excl + c.x + c.y + c.z);
-        if (tid == BLOCK - 1) s_bin[LOCAL_NBINS] = m;
+        u32 run = incl - tot;
+        for (int i = 0; i < wave; ++i) run += s_wsum[i];
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const u32 c0 = cw[i] & 0xFFFFu, c1 = cw[i] >> 16;
+            s_cw[WPT * tid + i] = run | ((run + c0) << 16);
+            run += c0 + c1;
+        }
+        if (tid == BLOCK - 1) s_cw[WORDS] = m;
     }
     __syncthreads();
+    const u16* s_st = reinterpret_cast<const u16*>(s_cw);   // start of bin b (little endian: the low half is the even bin)
 
     // 3. records -> LDS in bin order
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const u32 p = (u32)j * BLOCK + tid;
         if ((u32)j * BLOCK < m && p < m) {
-            const u32 slot = s_bin[(key[j] >> a.bin_shift) & a.bin_mask] + r[j];
+            const u32 slot = (u32)s_st[(key[j] >> a.bin_shift) & (u32)(NB - 1)] + r[j];
             s_rec[slot] = ((u64)key[j] << 32) | (u64)val[j];
         }
     }
     __syncthreads();
 
-    // 4. final place of slot p: its bin's start + the records of the bin that compare smaller (key, then suffix)
+    // 4. final place of slot p: its bin's start + the records of the bin that compare smaller (key, then suffix);
+    //    two records of the bin per step (one ds_read2_b64)
     u64 rec[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -463,10 +486,14 @@ __global__ __launch_bounds__(LOCAL_BLOCK, 4) void local_finish_kernel(LocalArgs 
         rec[j] = 0; r[j] = 0;
         if ((u32)j * BLOCK < m && p < m) {
             const u64 x = s_rec[p];
-            const u32 bin = ((u32)(x >> 32) >> a.bin_shift) & a.bin_mask;
-            const u32 lo = s_bin[bin], hi = s_bin[bin + 1];
+            const u32 bin = ((u32)(x >> 32) >> a.bin_shift) & (u32)(NB - 1);
+            const u32 lo = s_st[bin], hi = s_st[bin + 1];
             u32 cnt = 0;
-            for (u32 q = lo; q < hi; ++q) cnt += (s_rec[q] < x) ? 1u : 0u;
+            for (u32 q = lo; q < hi; q += 2) {
+                const u64 y0 = s_rec[q], y1 = s_rec[q + 1];   // (s_rec[m] may be read: padded, never counted)
+                cnt += (y0 < x) ? 1u : 0u;
+                cnt += (q + 1 < hi && y1 < x) ? 1u : 0u;
+            }
             rec[j] = x;
             r[j] = lo + cnt;
         }
