@@ -414,7 +414,8 @@ typedef struct sa_hip_build_stats {
     uint32_t widen_fused;        /* 1: the int64 copy of sa_hip_index_build_device64 came out of the sort's last pass       */
     uint32_t narrow48;           /* 1: keys of 41..56 bits sorted as 10-byte records (u32 + u16 key parts + u32 index): kernels [1] =
                                   *    text_top_pass_kernel<512, true>, [2] / [3] = seg48_onesweep_kernel                           */
-    uint32_t lite_flags;         /* 1: the first flags pass wrote no flag array (near-random text: active records staged per tile)  */
+    uint32_t lite_flags;         /* 1: the first flags pass wrote no flag array (near-random text: active records staged per tile);
+                                  * 2: there was no such pass at all -- the local pass of the three-pass plan did its work per sub-bucket */
     uint64_t period_resolved;    /* suffixes ordered by the periodic-run shortcut (long repeats: period_finish.hpp)              */
     uint32_t split_plan;         /* > 0 (= rb, the key bits of the split): the narrow sort ran as THREE passes over the records (radix_split.hpp): kernels [2] = seg_split_kernel<512,24>
                                   *    (one launch: the records of a bucket grouped by their next rb <= 10 key bits), [3] = local_finish_kernel (one

@@ -938,6 +938,9 @@ struct NarrowWorkspace {
     u32 split_max_seen = 0;        // largest sub-bucket of the last sort that looked (0: the plan was not considered)
     u32* split_hist = nullptr;     // [RADIX][SPLIT_NB]
     u32* split_base = nullptr;     // [RADIX][SPLIT_NB]
+    u32* split_cursor = nullptr;   // [RADIX][SPLIT_NB]: the ATOMIC form's claims
+    bool split_atomic = true;      // SA_HIP_SPLIT_ATOMIC=0: the split pass with published counts and a look-back per bucket instead of claims by global atomics
+                                   // (measured: 4.25 against 3.05-3.45 ms at n = 1e9, profiles/r04_split_plan_atomic_ab.log)
     u32* split_sub = nullptr;      // [(RADIX << SPLIT_BITS) + 1] sub-bucket starts | [16] largest group per level
     u64* split_status = nullptr;   // [split_tiles][SPLIT_NB], allocated with the first sort that takes the plan
     u32 split_tiles = 0;
@@ -949,6 +952,8 @@ struct NarrowWorkspace {
     u32 split_cap = LOCAL_CAP;     // SA_HIP_SPLIT_CAP (tests: a smaller bound makes small texts take more levels)
     int split_rb = 0;              // level of the last sort that took the plan
     int local_bin_bits = 12;       // SA_HIP_LOCAL_BINS=11: 2048 bins in the local pass
+    bool split_flags = true;       // SA_HIP_SPLIT_FLAGS=0: the first flags pass stays a pass of its own
+    bool split_flags_done = false; // of the last sort: the local pass has written the directory and staged the active records
     int split_items = 28;          // SA_HIP_SPLIT_ITEMS=24 / 28 / 32: tiles of 12288 / 14336 / 16384 records in the split pass (32 spills 33 registers)
     static size_t hist_bytes() { return (size_t)NARROW_MAX_PASSES * RADIX * RADIX * sizeof(u32); }
     int init() {
@@ -959,9 +964,12 @@ struct NarrowWorkspace {
         SA_HIP_CHECK(hipMalloc(&map_dev, sizeof(CodeMap)));
         SA_HIP_CHECK(hipMalloc(&split_hist, split_table_bytes()));
         SA_HIP_CHECK(hipMalloc(&split_base, split_table_bytes()));
+        SA_HIP_CHECK(hipMalloc(&split_cursor, split_table_bytes()));
         SA_HIP_CHECK(hipMalloc(&split_sub, (split_sub_words() + 16) * sizeof(u32)));
         SA_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host_word), 64, hipHostMallocDefault));
         if (const char* e = diag_env("SA_HIP_SPLIT")) split_enabled = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_SPLIT_ATOMIC")) split_atomic = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_SPLIT_FLAGS")) split_flags = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_LOCAL_BINS")) local_bin_bits = (atoi(e) == 11) ? 11 : 12;
         if (const char* e = diag_env("SA_HIP_SPLIT_ITEMS")) { const int v = atoi(e); split_items = (v == 24 || v == 28) ? v : 32; }
         if (const char* e = diag_env("SA_HIP_SPLIT_CAP")) { const int v = atoi(e); if (v >= 64 && v <= (int)LOCAL_CAP) split_cap = (u32)v; }
@@ -986,12 +994,13 @@ struct NarrowWorkspace {
         if (map_dev) (void)hipFree(map_dev);
         if (split_hist) (void)hipFree(split_hist);
         if (split_base) (void)hipFree(split_base);
+        if (split_cursor) (void)hipFree(split_cursor);
         if (split_sub) (void)hipFree(split_sub);
         if (split_status) (void)hipFree(split_status);
         if (host_word) (void)hipHostFree(host_word);
         map_dev = nullptr;
         plan = nullptr; hist = nullptr; base = nullptr; tickets = nullptr;
-        split_hist = split_base = split_sub = nullptr; split_status = nullptr; split_tiles = 0; host_word = nullptr;
+        split_hist = split_base = split_sub = split_cursor = nullptr; split_status = nullptr; split_tiles = 0; host_word = nullptr;
     }
 };
 
@@ -1071,7 +1080,7 @@ inline void launch_text_low_pass(void* ctx, hipStream_t stream, const SortPassAr
 // record less written here, 4 less read by whoever consumes the keys).
 inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_t stream, u64* keysA, u32* valsA, u64* keysB,
                              u32* valsB, u32 n, int begin_bit, u64** keys_res, u32** vals_res, const TextSource* src = nullptr,
-                             bool keep_narrow = false, int64_t* vals_res64 = nullptr) {
+                             bool keep_narrow = false, int64_t* vals_res64 = nullptr, const LocalFlagsRequest* flags_req = nullptr) {
     int rc;
     const int lo_bits = 56 - begin_bit;                       // 1 .. 32
     const int np = (lo_bits + RADIX_BITS - 1) / RADIX_BITS;   // narrow passes, 1 .. 4
@@ -1119,6 +1128,7 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
     // Three-pass plan (radix_split.hpp): the records of a bucket are grouped by their next rb key bits, then every group is
     // ordered completely in LDS -- when the largest group fits (near-random text; the device's own count decides)
     nw.split_used = false;
+    nw.split_flags_done = false;
     nw.split_max_seen = 0;
     if (try_split) {
         const int hb = (lo_bits - LOCAL_BIN_BITS < SPLIT_BITS) ? lo_bits - LOCAL_BIN_BITS : SPLIT_BITS;   // key bits the histogram looks at
@@ -1147,23 +1157,30 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
             const u32 dmask = (1u << rb) - 1u;
             hipLaunchKernelGGL(split_scan_kernel, dim3(RADIX), dim3(SPLIT_NB), 0, stream, (const u32*)nw.split_hist, nw.plan, hb, rb,
                                nw.split_base, nw.split_sub);
-            if ((rc = nw.ensure_split_status(split_flat_max, stream))) return rc;
+            if (!nw.split_atomic && (rc = nw.ensure_split_status(split_flat_max, stream))) return rc;
+            if (nw.split_atomic) SA_HIP_CHECK(hipMemsetAsync(nw.split_cursor, 0, NarrowWorkspace::split_table_bytes(), stream));
             if (++ws.epoch >= (1u << 30)) {
                 SA_HIP_CHECK(hipMemsetAsync(ws.status, 0, (size_t)ws.max_tiles * RADIX * sizeof(u64), stream));
                 ws.epoch = 1;
             }
-            if (ws.epoch <= nw.split_epoch)   // the sort's epoch has wrapped since the last split pass
+            if (!nw.split_atomic && ws.epoch <= nw.split_epoch)   // the sort's epoch has wrapped since the last split pass
                 SA_HIP_CHECK(hipMemsetAsync(nw.split_status, 0, (size_t)nw.split_tiles * SPLIT_NB * sizeof(u64), stream));
             nw.split_epoch = ws.epoch;
             SplitPassArgs a;
             a.keys_in = reinterpret_cast<const u32*>(keysB); a.vals_in = valsB;
             a.keys_out = reinterpret_cast<u32*>(keysA); a.vals_out = valsA;
             a.plan = nw.plan; a.shift = dshift; a.mask = dmask; a.digit_base = nw.split_base; a.status = nw.split_status;
-            a.ticket = nw.tickets; a.epoch = ws.epoch; a.dstat = ws.dstat; a.incl_mask = SA_INCL_MASK;
+            a.ticket = nw.tickets; a.epoch = ws.epoch; a.dstat = ws.dstat; a.incl_mask = SA_INCL_MASK; a.cursor = nw.split_cursor;
             if ((rc = ws.timer.start(stream, 2))) return rc;
-            if (nw.split_items == 32) hipLaunchKernelGGL((seg_split_kernel<512, 32>), dim3(split_flat_max), dim3(512), 0, stream, a);
-            else if (nw.split_items == 28) hipLaunchKernelGGL((seg_split_kernel<512, 28>), dim3(split_flat_max), dim3(512), 0, stream, a);
-            else hipLaunchKernelGGL((seg_split_kernel<512, 24>), dim3(split_flat_max), dim3(512), 0, stream, a);
+            if (nw.split_atomic) {
+                if (nw.split_items == 32) hipLaunchKernelGGL((seg_split_kernel<512, 32, true>), dim3(split_flat_max), dim3(512), 0, stream, a);
+                else if (nw.split_items == 28) hipLaunchKernelGGL((seg_split_kernel<512, 28, true>), dim3(split_flat_max), dim3(512), 0, stream, a);
+                else hipLaunchKernelGGL((seg_split_kernel<512, 24, true>), dim3(split_flat_max), dim3(512), 0, stream, a);
+            } else {
+                if (nw.split_items == 32) hipLaunchKernelGGL((seg_split_kernel<512, 32, false>), dim3(split_flat_max), dim3(512), 0, stream, a);
+                else if (nw.split_items == 28) hipLaunchKernelGGL((seg_split_kernel<512, 28, false>), dim3(split_flat_max), dim3(512), 0, stream, a);
+                else hipLaunchKernelGGL((seg_split_kernel<512, 24, false>), dim3(split_flat_max), dim3(512), 0, stream, a);
+            }
             if ((rc = ws.timer.stop(stream, (u64)n * 16u))) return rc;
             ws.pass_records += n; ws.pass_bytes += (u64)n * 16u; ws.passes += 1;
             LocalArgs l;
@@ -1174,9 +1191,27 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
             l.bin_shift = rest_bits - bb;
             l.dstat = ws.dstat;
             const u64 local_bytes = (u64)n * 16u + (vals_res64 ? (u64)n * 8u : 0u);
+            // the build's first flags pass inside the local pass, when the caller asks for it and provides the buffers
+            nw.split_flags_done = false;
+            l.dir = DirArgs{}; l.counts = nullptr; l.lite = LiteArgs{}; l.lo_shift = begin_bit; l.rb = rb; l.n = n;
+            bool with_flags = false;
+            if (nw.split_flags && flags_req && flags_req->prepare) {
+                const int fr = flags_req->prepare(flags_req->ctx, (u32)RADIX << rb, &l);
+                if (fr < 0) return fr;
+                // (the slice of the directory that belongs to a sub-bucket is read off the local pass's bin starts: the bins must be
+                //  at least as fine as the directory, and the directory's bits must lie inside the narrow key)
+                with_flags = (fr == 0) && l.dir.dir && l.dir.dbits >= 8 + rb && l.dir.dbits - 8 - rb <= bb && l.dir.dbits - 8 <= lo_bits;
+            }
             if ((rc = ws.timer.start(stream, 3))) return rc;
-            if (bb == 12) hipLaunchKernelGGL(local_finish_kernel<12>, dim3((u32)RADIX << rb), dim3(LOCAL_BLOCK), 0, stream, l);
-            else hipLaunchKernelGGL(local_finish_kernel<11>, dim3((u32)RADIX << rb), dim3(LOCAL_BLOCK), 0, stream, l);
+            const dim3 lgrid((u32)RADIX << rb), lblock(LOCAL_BLOCK);
+            if (with_flags) {
+                if (bb == 12) hipLaunchKernelGGL((local_finish_kernel<12, true>), lgrid, lblock, 0, stream, l);
+                else hipLaunchKernelGGL((local_finish_kernel<11, true>), lgrid, lblock, 0, stream, l);
+                nw.split_flags_done = true;
+            } else {
+                if (bb == 12) hipLaunchKernelGGL((local_finish_kernel<12, false>), lgrid, lblock, 0, stream, l);
+                else hipLaunchKernelGGL((local_finish_kernel<11, false>), lgrid, lblock, 0, stream, l);
+            }
             if ((rc = ws.timer.stop(stream, local_bytes))) return rc;
             ws.pass_records += n; ws.pass_bytes += local_bytes; ws.passes += 1;
             SA_HIP_CHECK(hipGetLastError());

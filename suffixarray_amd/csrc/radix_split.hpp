@@ -32,6 +32,7 @@
 //
 // Replaces, by function only, the same libsais stages as radix_sort.hpp; no shared code or structure.
 #pragma once
+#include "flags_common.hpp"
 
 namespace sa {
 
@@ -219,9 +220,13 @@ struct SplitPassArgs {
     u32 epoch;
     DeviceStatus* dstat;
     u32 incl_mask;
+    u32* cursor;           // ATOMIC form: [RADIX buckets][SPLIT_NB] records placed so far (zeroed by the host)
 };
 
-template <bool FULL, int BLOCK, int ITEMS>
+// ATOMIC: a tile claims its place in a bin with one returning global atomic per non-empty bin instead of publishing its counts
+// and looking back over its predecessors -- the pass need not be stable, so the tiles of a bucket need no order among
+// themselves, and nothing waits for another workgroup.
+template <bool FULL, int BLOCK, int ITEMS, bool ATOMIC>
 __device__ __forceinline__ void split_tile(const SplitPassArgs& a, const u32 flat, const u32 first_flat, const u32 bucket,
                                            const u32 start, const u32 tile_n, u32* s_keys, u32* s_cnt, u32* s_gdelta, u32* s_wsum) {
     static_assert(SPLIT_NB == 2 * BLOCK, "two bins per thread");
@@ -251,7 +256,12 @@ __device__ __forceinline__ void split_tile(const SplitPassArgs& a, const u32 fla
 
     // 3. bin counts -> aggregate published -> exclusive scan over the bins
     const uint2 c = *reinterpret_cast<const uint2*>(s_cnt + 2 * tid);
-    {
+    u32 claim0 = 0, claim1 = 0;
+    if (ATOMIC) {   // requested now, needed for the stores
+        u32* cur = a.cursor + (size_t)bucket * SPLIT_NB + 2 * tid;
+        if (c.x) claim0 = atomicAdd(cur, c.x);
+        if (c.y) claim1 = atomicAdd(cur + 1, c.y);
+    } else {
         const u64 fl = (flat == first_flat) ? FLAG_INCL : FLAG_AGG;
         __hip_atomic_store(&a.status[(u64)flat * SPLIT_NB + 2 * tid], pack_status(a.epoch, fl, c.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&a.status[(u64)flat * SPLIT_NB + 2 * tid + 1], pack_status(a.epoch, fl, c.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -280,8 +290,8 @@ __device__ __forceinline__ void split_tile(const SplitPassArgs& a, const u32 fla
 
     // 5. look-back inside the bucket, both bins of the thread at once
     {
-        u32 p0 = 0, p1 = 0;
-        if (flat > first_flat) {
+        u32 p0 = claim0, p1 = claim1;
+        if (!ATOMIC && flat > first_flat) {
             lookback_prefix_pair(a.status, flat, first_flat, 2u * (u32)tid, a.epoch, a.dstat, p0, p1);
             if (((flat - first_flat) & a.incl_mask) == a.incl_mask) {
                 __hip_atomic_store(&a.status[(u64)flat * SPLIT_NB + 2 * tid], pack_status(a.epoch, FLAG_INCL, p0 + c.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -328,7 +338,7 @@ __device__ __forceinline__ void split_tile(const SplitPassArgs& a, const u32 fla
     }
 }
 
-template <int BLOCK, int ITEMS>
+template <int BLOCK, int ITEMS, bool ATOMIC>
 __global__ __launch_bounds__(BLOCK, 4) void seg_split_kernel(SplitPassArgs a) {
     constexpr u32 TILE = BLOCK * ITEMS;
     __shared__ __attribute__((aligned(16))) u32 s_keys[TILE];   // reused for the values
@@ -369,8 +379,8 @@ __global__ __launch_bounds__(BLOCK, 4) void seg_split_kernel(SplitPassArgs a) {
     const u32 first_flat = s_t[bucket];
     const u32 start = s_b[bucket] + (flat - first_flat) * TILE;
     const u32 rest = s_b[bucket + 1] - start;
-    if (rest >= TILE) split_tile<true, BLOCK, ITEMS>(a, flat, first_flat, bucket, start, TILE, s_keys, s_cnt, s_gdelta, s_wsum);
-    else split_tile<false, BLOCK, ITEMS>(a, flat, first_flat, bucket, start, rest, s_keys, s_cnt, s_gdelta, s_wsum);
+    if (rest >= TILE) split_tile<true, BLOCK, ITEMS, ATOMIC>(a, flat, first_flat, bucket, start, TILE, s_keys, s_cnt, s_gdelta, s_wsum);
+    else split_tile<false, BLOCK, ITEMS, ATOMIC>(a, flat, first_flat, bucket, start, rest, s_keys, s_cnt, s_gdelta, s_wsum);
 }
 
 // ---- local finish: one sub-bucket per workgroup, ordered completely in LDS ------------------------------------------------
@@ -383,12 +393,28 @@ struct LocalArgs {
     const u32* sub;        // [nsub + 1] starts of the sub-buckets
     int bin_shift;         // bin = (key >> bin_shift) & (2^BB - 1): the key bits right below the sub-bucket's
     DeviceStatus* dstat;
+    // FLAGS: the build's first flags pass folded in (sa_build.hpp: flags_lite_kernel).  A sub-bucket holds every slot that
+    // shares its 8 + rb key bits, so which slots are tied with a neighbour, and which directory buckets a slot owns, is
+    // decided inside it: the pass over the sorted keys (4 n bytes read, 1.6 ms at n = 1e9) is not needed.
+    DirArgs dir;           // the query path's bucket directory (dbits >= 8 + rb)
+    uint2* counts;         // [sub-buckets] {active slots, active heads}
+    LiteArgs lite;         // staging rows [sub-buckets][LITE_CAP] (lite.sa unused)
+    int lo_shift;          // full key of a slot = (bucket << 56) | (narrow key << lo_shift)
+    int rb;
+    u32 n;
+};
+
+// What the caller of the sort provides when it wants the flags work done by the local pass: called once the level is known
+// with the number of sub-buckets, fills dir / counts / lite (buffers sized for that many rows) -- or returns non-zero to decline.
+struct LocalFlagsRequest {
+    int (*prepare)(void* ctx, u32 nsub, LocalArgs* l) = nullptr;
+    void* ctx = nullptr;
 };
 
 // BB: bin bits (11 or 12).  The counters are 16 bits wide, two per LDS word (a sub-bucket holds <= 8192 records), so that
 // 4096 bins cost the 8 KB that 2048 32-bit counters did: 1.8 instead of 3.7 records per bin at n = 1e9, and it is the
 // LARGEST bin among a wave's 64 records that sets the trip count of the counting loop.
-template <int BB>
+template <int BB, bool FLAGS>
 __global__ __launch_bounds__(LOCAL_BLOCK, 4) void local_finish_kernel(LocalArgs a) {
     constexpr int BLOCK = LOCAL_BLOCK, ITEMS = LOCAL_ITEMS;
     constexpr int NB = 1 << BB, WORDS = NB / 2, WPT = WORDS / BLOCK;   // packed counter words, words per thread in the scan
@@ -398,16 +424,28 @@ __global__ __launch_bounds__(LOCAL_BLOCK, 4) void local_finish_kernel(LocalArgs 
     __shared__ __attribute__((aligned(16))) u32 s_cw[WORDS + 4];   // counts, then starts, of bins 2w | 2w + 1 << 16; [WORDS] low half: start[NB] = m
     __shared__ u32 s_wsum[BLOCK / WAVE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ u32 s_na, s_nh;   // FLAGS: active slots / active heads of the sub-bucket
     const u32 s = a.sub[blockIdx.x];
     const u32 m = a.sub[blockIdx.x + 1] - s;
-    if (m == 0) return;
+    // FLAGS: the directory buckets of this sub-bucket's key prefix are [dfirst, dfirst + nd)
+    const int g2 = FLAGS ? a.dir.dbits - 8 - a.rb : 0;
+    const u32 dfirst = FLAGS ? (blockIdx.x << g2) : 0u;
+    const u32 nd = FLAGS ? (1u << g2) : 0u;   // directory buckets of this sub-bucket (<= WORDS: the host has checked)
+    if (FLAGS && tid == 0 && blockIdx.x == gridDim.x - 1) a.dir.dir[1u << a.dir.dbits] = a.n;   // the end marker
+    if (m == 0) {
+        if (FLAGS) {   // every bucket of an empty sub-bucket points at the next slot
+            for (u32 e = tid; e < nd; e += BLOCK) a.dir.dir[dfirst + e] = s;
+            if (tid == 0) a.counts[blockIdx.x] = make_uint2(0u, 0u);
+        }
+        return;
+    }
     if (m > LOCAL_CAP) {   // cannot happen: the host has seen the largest sub-bucket
         if (tid == 0) __hip_atomic_store(&a.dstat->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     const u32* kin = a.keys_in + s;
     const u32* vin = a.vals_in + s;
-    if (m == 1) {
+    if (!FLAGS && m == 1) {
         if (tid == 0) {
             const u32 k = kin[0], v = vin[0];
             a.keys_out[s] = k; a.vals_out[s] = v;
@@ -417,6 +455,7 @@ __global__ __launch_bounds__(LOCAL_BLOCK, 4) void local_finish_kernel(LocalArgs 
     }
 #pragma unroll
     for (int i = 0; i < WPT; ++i) s_cw[WPT * tid + i] = 0;
+    if (FLAGS && tid == 0) { s_na = 0; s_nh = 0; }
     __syncthreads();
 
     // 1. load; place inside the bin from one returning LDS atomic per record
@@ -465,6 +504,10 @@ __global__ __launch_bounds__(LOCAL_BLOCK, 4) void local_finish_kernel(LocalArgs 
     }
     __syncthreads();
     const u16* s_st = reinterpret_cast<const u16*>(s_cw);   // start of bin b (little endian: the low half is the even bin)
+    // FLAGS: dir[bkt] = first slot whose key's top bits are >= bkt = s + the records of the sub-bucket in lower buckets.  The bins
+    // are the key bits right below the sub-bucket's and at least as fine as the directory (the host has checked g2 <= BB), so
+    // that count is the start of the bucket's first bin: the slice of the directory is the bin-start table, subsampled
+    if (FLAGS) for (u32 e = tid; e < nd; e += BLOCK) a.dir.dir[dfirst + e] = s + (u32)s_st[e << (BB - g2)];
 
     // 3. records -> LDS in bin order
 #pragma unroll
@@ -504,9 +547,15 @@ __global__ __launch_bounds__(LOCAL_BLOCK, 4) void local_finish_kernel(LocalArgs 
         const u32 p = (u32)j * BLOCK + tid;
         if ((u32)j * BLOCK < m && p < m) s_rec[r[j]] = rec[j];
     }
+    if (FLAGS && tid == 0) s_rec[m] = ~0ull;   // (the slot after the last one: never equal to a key)
     __syncthreads();
 
-    // 5. out, coalesced
+    // 5. out, coalesced: nothing but the loads and stores, unrolled -- this loop is what the pass's bandwidth hangs on (as a rolled
+    //    loop over the slots: 4.9 -> 7.5 ms at n = 1e9; with a per-slot flags body inside its sixteen copies: 6.8-7.3 ms; a second
+    //    walk over the sorted keys after it: 6.2 ms).  FLAGS asks one more thing of it: is the NEXT slot's key the same?  (the
+    //    neighbour comes with the same LDS instruction.)  Only then -- 0.2 % of the slots of a near-random text -- the slot looks
+    //    back as well and stages what is tied: itself when it starts the group, its successor always.  The rows of a
+    //    sub-bucket arrive in any order; lite_gather_kernel puts a row into slot order.
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const u32 p = (u32)j * BLOCK + tid;
@@ -515,6 +564,32 @@ __global__ __launch_bounds__(LOCAL_BLOCK, 4) void local_finish_kernel(LocalArgs 
             a.keys_out[s + p] = (u32)(x >> 32);
             a.vals_out[s + p] = (u32)x;
             if (a.vals_out64) a.vals_out64[s + p] = (int64_t)(u32)x;
+            if (FLAGS) {
+                const u64 xn = s_rec[p + 1];   // (s_rec[m] = ~0)
+                if ((u32)(xn >> 32) == (u32)(x >> 32) && p + 1 < m) {
+                    const bool starts = (p == 0) || ((u32)(s_rec[p - 1] >> 32) != (u32)(x >> 32));
+                    u32 at = atomicAdd(&s_na, starts ? 2u : 1u);
+                    if (starts) {
+                        atomicAdd(&s_nh, 1u);
+                        if (at < LITE_CAP) {
+                            const u64 row = (u64)blockIdx.x * LITE_CAP + at;
+                            a.lite.st_pos[row] = s + p; a.lite.st_idx[row] = (u32)x; a.lite.st_head[row] = 1;
+                        }
+                        ++at;
+                    }
+                    if (at < LITE_CAP) {
+                        const u64 row = (u64)blockIdx.x * LITE_CAP + at;
+                        a.lite.st_pos[row] = s + p + 1; a.lite.st_idx[row] = (u32)xn; a.lite.st_head[row] = 0;
+                    }
+                }
+            }
+        }
+    }
+    if (FLAGS) {
+        sync_lds();
+        if (tid == 0) {
+            a.counts[blockIdx.x] = make_uint2(s_na, s_nh);
+            if (s_na > LITE_CAP) __hip_atomic_store(a.lite.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -171,31 +171,6 @@ __global__ __launch_bounds__(BLD_BLOCK) void keygen_kernel(const u8* __restrict_
 // dir[bkt] = first slot whose key has top-dbits >= bkt.  Slot j owns the buckets (top(K[j-1]), top(K[j])];
 // runs of up to DIR_INLINE buckets are written here, longer ones (unused codes of the compacted
 // alphabet leave holes of up to 2^dbits / 8 buckets) are queued for dir_fill_kernel.
-constexpr u32 DIR_INLINE = 40;   // 8 queued the (2^(dbits-25) * 8 + 1)-bucket holes behind every 5-character prefix of a 27-letter text: 531 441 atomics on one counter, +5 ms
-constexpr u32 DIR_PIECE = 1u << 14;
-struct DirArgs {
-    u32* dir;        // [2^dbits + 1], or nullptr
-    int dbits;
-    uint4* gaps;     // queue of {first bucket, last bucket, value, -}
-    u32* gap_count;  // zeroed by the host
-    u32 gap_cap;
-    DeviceStatus* dstat;
-};
-__device__ __forceinline__ void dir_emit(const DirArgs& d, u32 first, u32 last, u32 value) {
-    if (last - first < DIR_INLINE) {
-        for (u32 bkt = first; bkt <= last; ++bkt) d.dir[bkt] = value;
-    } else {
-        // queued in pieces of at most DIR_PIECE buckets: dir_fill_kernel gives one piece to one workgroup, and the
-        // holes of a compacted alphabet reach 2^dbits / 8 buckets (one workgroup filling 2M entries took 0.2 ms)
-        for (u64 f = first; f <= (u64)last; f += DIR_PIECE) {
-            const u64 l = (f + DIR_PIECE - 1 < (u64)last) ? f + DIR_PIECE - 1 : (u64)last;
-            const u32 slot = atomicAdd(d.gap_count, 1u);
-            if (slot < d.gap_cap) d.gaps[slot] = make_uint4((u32)f, (u32)l, value, 0u);
-            else __hip_atomic_store(&d.dstat->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // cannot happen: see gap_cap
-        }
-    }
-}
-
 // The directory is written early in the build; reading it once at the end leaves its 2^dbits * 4 bytes
 // (268 MB at the default 26 bits for n = 1e9, 4 MB at n = 1e7) in the memory-side cache for the first query batch
 // as far as they fit, as a directory built last would be.
@@ -353,14 +328,6 @@ __global__ __launch_bounds__(BLD_BLOCK) void flags_kernel(const u64* __restrict_
 // on this plan the tiny-group finisher normally resolves everything and nobody asks.  A tile with more than LITE_CAP
 // active slots (6.25 %: the tiny-group finisher's own limit is M * 16 <= n) raises *overflow and the build repeats the
 // pass in its full form.  The bucket directory is written exactly as above.
-constexpr u32 LITE_CAP = 256;
-struct LiteArgs {
-    const u32* sa;       // suffix per slot (the sort's values)
-    u32* st_pos;         // [tiles][LITE_CAP] slot
-    u32* st_idx;         // [tiles][LITE_CAP] suffix
-    u8* st_head;         // [tiles][LITE_CAP] 1 = first slot of its group
-    u32* overflow;       // set to 1 by a tile with more than LITE_CAP active slots
-};
 __global__ __launch_bounds__(BLD_BLOCK, 8) void flags_lite_kernel(NarrowKeys nk, u32 n, uint2* __restrict__ counts, DirArgs dirargs, LiteArgs o) {
     constexpr int STEPS = BLD_ITEMS / 4;
     static_assert(STEPS == 4, "sixteen slots per thread");
@@ -1319,7 +1286,7 @@ struct Builder {
     void destroy() {
         DevBuf* all[] = {&text, &keys0, &keys1, &vals0, &vals1, &flags, &counts, &small, &isa, &apos0, &apos1, &apos2, &aidx,
                          &gid, &rkeys0, &rkeys1, &ridx0, &ridx1, &lf, &tile_last, &carry, &sa_own, &partial, &qdir, &dbg, &done, &pilot,
-                         &gstart, &loc_tiles, &big_keys, &big_vals, &fin_flag, &fin_w0, &fin_left_gid, &qkeys2, &qskeys, &per_gd, &per_bad, &per_table, &per_dec, &per_tf, &per_carry};
+                         &gstart, &loc_tiles, &big_keys, &big_vals, &fin_flag, &fin_w0, &fin_left_gid, &lite_stage, &qkeys2, &qskeys, &per_gd, &per_bad, &per_table, &per_dec, &per_tf, &per_carry};
         for (DevBuf* b : all) b->release();
         radix.destroy();
         narrow.destroy();
@@ -1470,8 +1437,52 @@ struct Builder {
     bool flags_valid = true;          // the flag array holds the head bits of the current grouping
     LiteArgs lite{};
     NarrowKeys lite_nk{};
+    // The same work done by the local pass of the three-pass plan (radix_split.hpp: local_finish_kernel<., true>) on the
+    // sub-bucket it holds in LDS: this is what the sort calls once it knows how many sub-buckets there are.  The staging rows
+    // cannot live in a key buffer here (the pass still reads one and writes the other): a buffer of their own.
+    DevBuf lite_stage;
+    DirArgs split_dir{};
+    u32 lite_tiles = 0;   // rows of the staging area: tiles of the lite pass, or sub-buckets
+    static int split_flags_prepare(void* ctx, u32 nsub, LocalArgs* l) {
+        Builder* b = static_cast<Builder*>(ctx);
+        int rc = b->directory_layout(b->n);
+        if (rc) return rc;
+        if ((rc = b->counts.ensure((size_t)nsub * sizeof(uint2) + 64))) return rc;
+        if ((rc = b->lite_stage.ensure((size_t)nsub * LITE_CAP * 9 + 64))) return rc;
+        DirArgs d{};
+        d.dir = b->qdir.as<u32>();
+        d.dbits = b->q_dbits;
+        const u64 nb = (1ull << b->q_dbits) + 1;
+        d.gaps = reinterpret_cast<uint4*>(b->qdir.as<u8>() + dir_gap_offset(nb));
+        d.gap_cap = dir_gap_cap(nb);
+        d.gap_count = reinterpret_cast<u32*>(b->small.as<u8>() + 3584);
+        d.dstat = b->radix.dstat;
+        SA_HIP_CHECK(hipMemsetAsync(d.gap_count, 0, 4, b->stream));
+        b->lite.sa = nullptr;
+        b->lite.st_pos = b->lite_stage.as<u32>();
+        b->lite.st_idx = b->lite.st_pos + (size_t)nsub * LITE_CAP;
+        b->lite.st_head = reinterpret_cast<u8*>(b->lite.st_idx + (size_t)nsub * LITE_CAP);
+        b->lite.overflow = b->totals_dev() + 2;
+        SA_HIP_CHECK(hipMemsetAsync(b->lite.overflow, 0, 4, b->stream));
+        b->split_dir = d;
+        b->lite_tiles = nsub;
+        l->dir = d;
+        l->counts = b->counts.as<uint2>();
+        l->lite = b->lite;
+        return 0;
+    }
+    // ... and what is left to do after such a sort: the scan of the per-sub-bucket counts
+    int flags_after_split(const NarrowKeys& nk, u32* totals_host, bool* overflow) {
+        dir_ready = true;   // (every directory entry was written by the local pass: no queued runs)
+        lite_nk = nk;
+        int rc = scan_counts(lite_tiles, totals_host);
+        if (rc) return rc;
+        *overflow = lite_overflow_seen != 0;
+        return 0;
+    }
     int flags_lite_pass(const NarrowKeys& nk, u32 cnt, void* stage, u32* totals_host, bool* overflow) {
         const u32 tiles = div_up(cnt, BLD_TILE);
+        lite_tiles = tiles;
         int rc = directory_layout(cnt);
         if (rc) return rc;
         DirArgs d{};
@@ -1960,8 +1971,10 @@ struct Builder {
         if (narrow_path) {
             TextSource src;
             src.text = text.as<u8>(); src.b = b; src.k0 = k0;
+            LocalFlagsRequest freq;   // the first flags pass inside the sort's last pass, when the three-pass plan is taken
+            if (keep_narrow && lite_flags) { freq.prepare = &Builder::split_flags_prepare; freq.ctx = this; }
             if ((rc = radix_sort_narrow(radix, narrow, stream, keys0.as<u64>(), vals0.as<u32>(), keys1.as<u64>(), vals1.as<u32>(),
-                                        n32, begin_bit, &kres, &vres, text_pass ? &src : nullptr, keep_narrow, sa64_out))) return rc;
+                                        n32, begin_bit, &kres, &vres, text_pass ? &src : nullptr, keep_narrow, sa64_out, &freq))) return rc;
             if (sa64_out) stats.widen_fused = 1;
             stats.split_plan = narrow.split_used ? (u32)narrow.split_rb : 0u;
             stats.split_max = narrow.split_max_seen;
@@ -2006,10 +2019,12 @@ struct Builder {
             // has left free), the full form only when a tile overflows its staging row
             void* stage = (static_cast<void*>(kres) == keys0.p) ? keys1.p : keys0.p;
             bool overflow = false;
+            if (narrow_path && narrow.split_flags_done) { if ((rc = flags_after_split(nk, tot, &overflow))) return rc; }
+            else
             if ((rc = flags_lite_pass(nk, n32, stage, tot, &overflow))) return rc;
             if (overflow) { if ((rc = flags_and_counts(kres, n32, flags.as<u8>(), nullptr, nullptr, tot, false, &nk))) return rc; }
             else { flags_valid = false; staged = true; }
-            stats.lite_flags = staged ? 1u : 0u;
+            stats.lite_flags = staged ? ((narrow_path && narrow.split_flags_done) ? 2u : 1u) : 0u;
         } else
         if ((rc = flags_and_counts(kres, n32, flags.as<u8>(), nullptr, nullptr, tot, fuse_directory, keep_narrow ? &nk : nullptr))) return rc;
         if ((rc = check_device_status())) return rc;
@@ -2031,8 +2046,8 @@ struct Builder {
             if ((rc = lf.ensure(m0 + 64))) return rc;
             // first compaction: domain = whole SA
             if (staged)
-                hipLaunchKernelGGL(lite_gather_kernel, dim3(div_up(div_up(n32, BLD_TILE), 4)), dim3(256), 0, stream, (const uint2*)counts.as<uint2>(),
-                                   div_up(n32, BLD_TILE), (const u32*)totals_dev(), lite, apos0.as<u32>(), aidx.as<u32>(), gid.as<u32>());
+                hipLaunchKernelGGL(lite_gather_kernel, dim3(div_up(lite_tiles, 4)), dim3(256), 0, stream, (const uint2*)counts.as<uint2>(),
+                                   lite_tiles, (const u32*)totals_dev(), lite, apos0.as<u32>(), aidx.as<u32>(), gid.as<u32>());
             else
             launch_compact(flags.as<u8>(), n32, M, nullptr, sa, apos0.as<u32>(), aidx.as<u32>(), gid.as<u32>());
         }

@@ -159,11 +159,14 @@ def test_narrow_record_sort_matches_plain_sort(gpu, oracle, monkeypatch):
 def test_split_plan_matches_lsd_passes(gpu, oracle, monkeypatch):
     """The three-pass plan of the narrow sort (radix_split.hpp: top digit, split pass by the next rb key bits, every sub-bucket
     ordered completely in LDS) against the five-pass plan (SA_HIP_SPLIT=0: LSD passes inside the buckets): the same suffix
-    array bit for bit, verified on the device, the oracle's on two texts.  Uniform text at several sizes and forced key
-    lengths (levels rb = 1..8 by lowering the bound on a sub-bucket), DNA-like text, truncated builds whose ties must stay
-    in text order (k0 = L), the fused int64 copy; skewed and word text must DECLINE the plan (a sub-bucket beyond the bound)
-    and still come out right."""
+    array bit for bit, verified on the device, the oracle's on two texts.  Three ways: "F" = the plan with the build's first
+    flags pass folded into the local pass (directory + staged active records come out of the sub-buckets), "S" = the plan
+    with the flags pass on its own, "0" = LSD passes.  The query ranges of a batch (hits, misses, edge patterns) must agree
+    in all three -- they go through the bucket directory -- and with the oracle on two texts.  Uniform text at several sizes
+    and forced key lengths (levels rb = 2..8 by lowering the bound on a sub-bucket), DNA-like text, truncated builds whose ties
+    must stay in text order (k0 = L), the fused int64 copy; skewed text must DECLINE the plan and still come out right."""
     from suffixarray_amd import synth
+    import cases
     rng = np.random.default_rng(14)
     dna = rng.choice(np.frombuffer(b"acgt", np.uint8), 5_000_000)
     skew = rng.choice(np.array([97, 98, 99, 100, 122], dtype=np.uint8), 6_000_000, p=[0.9, 0.04, 0.03, 0.02, 0.01])
@@ -183,9 +186,11 @@ def test_split_plan_matches_lsd_passes(gpu, oracle, monkeypatch):
             monkeypatch.setenv("SA_HIP_SPLIT_CAP", str(cap))
         else:
             monkeypatch.delenv("SA_HIP_SPLIT_CAP", raising=False)
-        got = {}
-        for mode in ("1", "0"):
-            monkeypatch.setenv("SA_HIP_SPLIT", mode)
+        pats = cases.query_patterns(t, 3000, np.random.default_rng(5), maxlen=24)
+        got, ranges = {}, {}
+        for mode in ("F", "S", "0"):
+            monkeypatch.setenv("SA_HIP_SPLIT", "0" if mode == "0" else "1")
+            monkeypatch.setenv("SA_HIP_SPLIT_FLAGS", "1" if mode == "F" else "0")
             with gpu.DeviceIndex(t.size, 0) as idx:
                 try:
                     idx.build(t, L)
@@ -201,20 +206,24 @@ def test_split_plan_matches_lsd_passes(gpu, oracle, monkeypatch):
                     assert st["split_max"] > 0 and (st["split_plan"] > 0) == (st["split_max"] <= (cap or 8192)), (name, st)
                     assert taken is None or (st["split_plan"] > 0) == taken, (name, st)
                     levels.add(st["split_plan"])
-                assert idx.verify() == 0, (name, st)
+                assert idx.verify() == 0, (name, mode, st)
                 got[mode] = idx.sa_u32().copy()
-        if got["1"] is None or got["0"] is None:
+                ranges[mode] = idx.query_batch(pats).copy()
+        if any(got.get(m) is None for m in ("F", "S", "0")):
             continue
-        assert np.array_equal(got["1"], got["0"]), name
+        assert np.array_equal(got["F"], got["0"]) and np.array_equal(got["S"], got["0"]), name
+        assert np.array_equal(ranges["F"], ranges["0"]) and np.array_equal(ranges["S"], ranges["0"]), name
         if name in ("d1", "d1_L8_cap500"):
             ref = oracle.sais(t).astype(np.uint32) if L == 0 else oracle.truncated_sa(t, L).astype(np.uint32)
-            assert np.array_equal(got["1"], ref), name
+            assert np.array_equal(got["F"], ref), name
+            assert np.array_equal(ranges["F"], oracle.query_batch(t, ref, L if L else 0xFFFFFFFF, pats)), name
     assert not failures, failures
     assert len(levels - {0}) >= 3, levels
     # the int64 copy leaves the local pass with the suffixes
     monkeypatch.delenv("SA_HIP_INITIAL_CHARS", raising=False)
     monkeypatch.delenv("SA_HIP_SPLIT_CAP", raising=False)
     monkeypatch.setenv("SA_HIP_SPLIT", "1")
+    monkeypatch.setenv("SA_HIP_SPLIT_FLAGS", "1")
     import torch
     t = runs[0][1]
     with gpu.DeviceIndex(t.size, 0) as idx:

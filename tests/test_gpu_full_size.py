@@ -103,6 +103,8 @@ def test_config3_n1e9_properties(gpu, oracle):
         idx.build(t)
         st = idx.build_stats()
         assert idx.verify() == 0, st                       # suffix array verified on the device
+        # the headline's plan (round 4): three passes over the records, sub-buckets of at most 8192 records at level 10
+        assert st["split_plan"] == 10 and 0 < st["split_max"] <= 8192 and st["radix_passes"] == 3, st
         got = idx.query_batch((buf, off))
         sa = idx.sa_u32()
         # libsais64 layout: the widened copy equals the 32-bit array (checked in slabs)

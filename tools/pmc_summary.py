@@ -22,7 +22,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SORT_KERNEL = "seg_onesweep_kernel<512, 24, false, true>"
 KEEP = ("onesweep", "text_top_pass", "query_kernel", "flags_kernel", "seg_hist", "top_hist", "byte_hist", "compact", "widen", "gather_kernel",
-        "loc_sort", "chunk_keys", "tiny_groups")
+        "loc_sort", "chunk_keys", "tiny_groups", "seg_split", "local_finish", "split_hist", "flags_lite", "lite_gather")
 
 
 def counter_file(tag, what):
@@ -62,19 +62,32 @@ def main():
             f"rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 {light}"]
 
     # ---- dominant sort kernel ----------------------------------------------------------------------------
-    f = [(g, v) for _, k, g, c, v in fetch if c == "FETCH_SIZE" and SORT_KERNEL in k]
-    w = [(g, v) for _, k, g, c, v in write if c == "WRITE_SIZE" and SORT_KERNEL in k]
+    # round 4: with the three-pass plan (radix_split.hpp) the dominant kernel of a D1 build is local_finish_kernel (8 + 8 bytes per
+    # record in, 8 + 8 out, + 8 for the int64 copy of bench.py's 64-bit build); the split pass is reported beside it
+    sort_kernel, alg_bytes, workload = SORT_KERNEL, 16.0 * n_chars, \
+        "bench.py default: D1 uniform27 N=1e9, k0=8 (40-bit keys): top-digit pass + 3 passes of this kernel + last pass per build"
+    if any("local_finish_kernel" in k for _, k, g, c, v in fetch):
+        sort_kernel, alg_bytes, workload = "local_finish_kernel", 24.0 * n_chars, \
+            "bench.py default: D1 uniform27 N=1e9, k0=8 (40-bit keys), three-pass plan: top-digit pass + split pass + ONE launch of this kernel per build (int64 copy fused)"
+    f = [(g, v) for _, k, g, c, v in fetch if c == "FETCH_SIZE" and sort_kernel in k]
+    w = [(g, v) for _, k, g, c, v in write if c == "WRITE_SIZE" and sort_kernel in k]
     if f and len(f) == len(w):
         big = max(g for g, _ in f)
         fb = [v * 1024.0 * 2.0 for g, v in f if g == big]
         wb = [v * 1024.0 for g, v in w if g == big]
-        j = {"kernel": SORT_KERNEL, "n_chars": n_chars,
-             "workload": "bench.py default: D1 uniform27 N=1e9, k0=8 (40-bit keys): top-digit pass + 3 passes of this kernel + last pass per build",
+        j = {"kernel": sort_kernel, "n_chars": n_chars,
+             "workload": workload,
              "launches": len(fb), "fetch_bytes_total": sum(fb), "write_bytes_total": sum(wb),
-             "traffic_bytes_per_launch": (sum(fb) + sum(wb)) / len(fb), "algorithmic_bytes_per_launch": 16.0 * n_chars,
+             "traffic_bytes_per_launch": (sum(fb) + sum(wb)) / len(fb), "algorithmic_bytes_per_launch": alg_bytes,
              "corrections": "FETCH_SIZE x2 (wide coalesced reads leave the L2 as 128-byte requests tallied at 64 B; calibrated with 8- and "
                             "4-byte-per-lane copy kernels, tools/sortbench.hip), WRITE_SIZE exact, counters in KiB",
              "commands": cmds, "source": tag}
+        sf = [v * 1024.0 * 2.0 for _, k, g, c, v in fetch if c == "FETCH_SIZE" and "seg_split_kernel" in k]
+        sw = [v * 1024.0 for _, k, g, c, v in write if c == "WRITE_SIZE" and "seg_split_kernel" in k]
+        if sf and len(sf) == len(sw):
+            j["split_pass"] = {"kernel": "seg_split_kernel<512, 28>", "launches": len(sf), "traffic_bytes_per_launch": (sum(sf) + sum(sw)) / len(sf),
+                               "fetch_bytes_per_launch": sum(sf) / len(sf), "write_bytes_per_launch": sum(sw) / len(sw),
+                               "algorithmic_bytes_per_launch": 16.0 * n_chars}
         json.dump(j, open(os.path.join(ROOT, "profiles", "pmc_onesweep.json"), "w"), indent=1)
         print(json.dumps(j, indent=1))
 
