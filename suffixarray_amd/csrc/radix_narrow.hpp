@@ -953,6 +953,8 @@ struct NarrowWorkspace {
     int split_rb = 0;              // level of the last sort that took the plan
     int local_bin_bits = 12;       // SA_HIP_LOCAL_BINS=11: 2048 bins in the local pass
     bool split_flags = true;       // SA_HIP_SPLIT_FLAGS=0: the first flags pass stays a pass of its own
+    bool local_big = false;        // SA_HIP_LOCAL_BIG=1: always the large form of the local pass (tests, A/B)
+    bool split_big = false;        // of the last sort: the local pass ran in its large form
     bool split_flags_done = false; // of the last sort: the local pass has written the directory and staged the active records
     int split_items = 28;          // SA_HIP_SPLIT_ITEMS=24 / 28 / 32: tiles of 12288 / 14336 / 16384 records in the split pass (32 spills 33 registers)
     static size_t hist_bytes() { return (size_t)NARROW_MAX_PASSES * RADIX * RADIX * sizeof(u32); }
@@ -968,6 +970,7 @@ struct NarrowWorkspace {
         SA_HIP_CHECK(hipMalloc(&split_sub, (split_sub_words() + 16) * sizeof(u32)));
         SA_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host_word), 64, hipHostMallocDefault));
         if (const char* e = diag_env("SA_HIP_SPLIT")) split_enabled = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_LOCAL_BIG")) local_big = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_SPLIT_ATOMIC")) split_atomic = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_SPLIT_FLAGS")) split_flags = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_LOCAL_BINS")) local_bin_bits = (atoi(e) == 11) ? 11 : 12;
@@ -1148,8 +1151,15 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
         SA_HIP_CHECK(hipMemcpyAsync(nw.host_word, nw.split_levels_dev(), 16 * sizeof(u32), hipMemcpyDeviceToHost, stream));
         SA_HIP_CHECK(hipStreamSynchronize(stream));
         int rb = -1;
-        for (int k = 1; k <= hb; ++k)
-            if (nw.host_word[k] <= nw.split_cap) { rb = k; break; }
+        bool big = nw.local_big;   // sub-buckets of up to LOCAL_CAP_BIG records: one workgroup per CU in the local pass
+        if (!big)
+            for (int k = 1; k <= hb; ++k)
+                if (nw.host_word[k] <= nw.split_cap) { rb = k; break; }
+        if (rb < 0 && nw.split_cap == LOCAL_CAP) {
+            for (int k = 1; k <= hb; ++k)
+                if (nw.host_word[k] <= LOCAL_CAP_BIG && lo_bits - k >= 12) { rb = k; big = true; break; }   // (its 4096 bins: 12 key bits below the sub-bucket's)
+            if (rb < 0) big = false;
+        }
         nw.split_max_seen = nw.host_word[rb > 0 ? rb : hb];
         if (rb > 0) {
             const int rest_bits = lo_bits - rb;   // >= LOCAL_BIN_BITS
@@ -1187,7 +1197,7 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
             l.keys_in = reinterpret_cast<const u32*>(keysA); l.vals_in = valsA;
             l.keys_out = reinterpret_cast<u32*>(keysB); l.vals_out = valsB; l.vals_out64 = vals_res64;
             l.sub = nw.split_sub;
-            const int bb = (rest_bits >= 12 && nw.local_bin_bits == 12) ? 12 : 11;
+            const int bb = (big || (rest_bits >= 12 && nw.local_bin_bits == 12)) ? 12 : 11;
             l.bin_shift = rest_bits - bb;
             l.dstat = ws.dstat;
             const u64 local_bytes = (u64)n * 16u + (vals_res64 ? (u64)n * 8u : 0u);
@@ -1203,15 +1213,19 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
                 with_flags = (fr == 0) && l.dir.dir && l.dir.dbits >= 8 + rb && l.dir.dbits - 8 - rb <= bb && l.dir.dbits - 8 <= lo_bits;
             }
             if ((rc = ws.timer.start(stream, 3))) return rc;
-            const dim3 lgrid((u32)RADIX << rb), lblock(LOCAL_BLOCK);
-            if (with_flags) {
+            const dim3 lgrid((u32)RADIX << rb), lblock(big ? LOCAL_BLOCK_BIG : LOCAL_BLOCK);
+            if (big) {
+                if (with_flags) hipLaunchKernelGGL((local_finish_kernel<12, true, LOCAL_BLOCK_BIG>), lgrid, lblock, 0, stream, l);
+                else hipLaunchKernelGGL((local_finish_kernel<12, false, LOCAL_BLOCK_BIG>), lgrid, lblock, 0, stream, l);
+            } else if (with_flags) {
                 if (bb == 12) hipLaunchKernelGGL((local_finish_kernel<12, true>), lgrid, lblock, 0, stream, l);
                 else hipLaunchKernelGGL((local_finish_kernel<11, true>), lgrid, lblock, 0, stream, l);
-                nw.split_flags_done = true;
             } else {
                 if (bb == 12) hipLaunchKernelGGL((local_finish_kernel<12, false>), lgrid, lblock, 0, stream, l);
                 else hipLaunchKernelGGL((local_finish_kernel<11, false>), lgrid, lblock, 0, stream, l);
             }
+            nw.split_flags_done = with_flags;
+            nw.split_big = big;
             if ((rc = ws.timer.stop(stream, local_bytes))) return rc;
             ws.pass_records += n; ws.pass_bytes += local_bytes; ws.passes += 1;
             SA_HIP_CHECK(hipGetLastError());

@@ -38,9 +38,11 @@ namespace sa {
 
 constexpr int SPLIT_BITS = 10;
 constexpr int SPLIT_NB = 1 << SPLIT_BITS;       // bins of the split pass (fewer are used when rb < SPLIT_BITS)
-constexpr u32 LOCAL_CAP = 8192;                 // records of a sub-bucket the local pass can hold
+constexpr u32 LOCAL_CAP = 8192;                 // records of a sub-bucket the local pass holds: 512 threads x 16, 74 KB of LDS, two workgroups per CU
 constexpr int LOCAL_BLOCK = 512;
 constexpr int LOCAL_ITEMS = (int)(LOCAL_CAP / LOCAL_BLOCK);
+constexpr u32 LOCAL_CAP_BIG = 16384;            // ... or, when no level fits that: 1024 threads x 16, 139 KB of LDS, one workgroup per CU
+constexpr int LOCAL_BLOCK_BIG = 1024;
 constexpr int LOCAL_BIN_BITS = 11;            // the key bits below a sub-bucket's that the plan asks for at least (bins of the local pass: 11 or 12 bits)
 constexpr int SPLIT_HIST_COPIES = 4;
 
@@ -414,13 +416,14 @@ struct LocalFlagsRequest {
 // BB: bin bits (11 or 12).  The counters are 16 bits wide, two per LDS word (a sub-bucket holds <= 8192 records), so that
 // 4096 bins cost the 8 KB that 2048 32-bit counters did: 1.8 instead of 3.7 records per bin at n = 1e9, and it is the
 // LARGEST bin among a wave's 64 records that sets the trip count of the counting loop.
-template <int BB, bool FLAGS>
-__global__ __launch_bounds__(LOCAL_BLOCK, 4) void local_finish_kernel(LocalArgs a) {
-    constexpr int BLOCK = LOCAL_BLOCK, ITEMS = LOCAL_ITEMS;
+template <int BB, bool FLAGS, int BLOCK = LOCAL_BLOCK>
+__global__ __launch_bounds__(BLOCK, 4) void local_finish_kernel(LocalArgs a) {
+    constexpr int ITEMS = LOCAL_ITEMS;
+    constexpr u32 CAP = (u32)BLOCK * ITEMS;
     constexpr int NB = 1 << BB, WORDS = NB / 2, WPT = WORDS / BLOCK;   // packed counter words, words per thread in the scan
     static_assert(WPT >= 1 && WPT * BLOCK == WORDS, "the scan covers the counters exactly");
-    static_assert(LOCAL_CAP < 65536, "16-bit counters and starts");
-    __shared__ __attribute__((aligned(16))) u64 s_rec[LOCAL_CAP + 2];
+    static_assert(CAP < 65536, "16-bit counters and starts");
+    __shared__ __attribute__((aligned(16))) u64 s_rec[CAP + 2];
     __shared__ __attribute__((aligned(16))) u32 s_cw[WORDS + 4];   // counts, then starts, of bins 2w | 2w + 1 << 16; [WORDS] low half: start[NB] = m
     __shared__ u32 s_wsum[BLOCK / WAVE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(LOCAL_BLOCK, 4) void local_finish_kernel(LocalArgs 
         }
         return;
     }
-    if (m > LOCAL_CAP) {   // cannot happen: the host has seen the largest sub-bucket
+    if (m > CAP) {   // cannot happen: the host has seen the largest sub-bucket
         if (tid == 0) __hip_atomic_store(&a.dstat->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }

@@ -1177,6 +1177,7 @@ struct Builder {
     CodeMap qmap;
     int q_b = 0, q_k0 = 0, q_dbits = 0;
     bool dir_ready = false;   // the directory in qdir belongs to qkeys
+    bool dir_by_local_pass = false;   // ... and was written by the three-pass plan's local pass, at the end of the sort
     int sector_search = 2;        // SA_HIP_SECTOR_SEARCH: interpolated scan inside a directory bucket (sa_query.hpp): 1 = 64-byte windows, 2 = 32-byte windows, 0 = binary search
 
     // Characters in the initial key.  Enough that, for an i.i.d. text with this byte
@@ -1474,6 +1475,7 @@ struct Builder {
     // ... and what is left to do after such a sort: the scan of the per-sub-bucket counts
     int flags_after_split(const NarrowKeys& nk, u32* totals_host, bool* overflow) {
         dir_ready = true;   // (every directory entry was written by the local pass: no queued runs)
+        dir_by_local_pass = true;
         lite_nk = nk;
         int rc = scan_counts(lite_tiles, totals_host);
         if (rc) return rc;
@@ -1590,6 +1592,7 @@ struct Builder {
             //  this read, 0.147 ms without, and the build time is the same within the noise)
             const u64 n16 = ((1ull << q_dbits) + 1) / 4;
             if (const char* e = diag_env("SA_HIP_DIR_TOUCH")) { if (atoi(e) == 0) return 0; }
+            if (dir_by_local_pass) return 0;   // written minutes of GPU time ago no longer: the sort's last pass stored it, in one sweep per sub-bucket
             hipLaunchKernelGGL(dir_touch_kernel, dim3(stream_grid(n16, 256)), dim3(256), 0, stream, qdir.as<uint4>(), n16,
                                reinterpret_cast<u32*>(small.as<u8>() + 3588));
             return 0;
@@ -1923,6 +1926,7 @@ struct Builder {
         qkeys = nullptr;
         qkeys32 = nullptr;
         dir_ready = false;
+        dir_by_local_pass = false;
         k2_ready = false;
         stats.widen_fused = 0;
         if (n == 0) return finish_stats();

@@ -177,6 +177,7 @@ def test_split_plan_matches_lsd_passes(gpu, oracle, monkeypatch):
             ("skew", skew, 13, 0, 0, False), ("words_k8", synth.d2_words(8_000_000), 8, 0, 0, None)]
     levels = set()
     failures = []
+    lsd = {}
     for name, t, k0, L, cap, taken in runs:
         if k0:
             monkeypatch.setenv("SA_HIP_INITIAL_CHARS", str(k0))
@@ -213,17 +214,34 @@ def test_split_plan_matches_lsd_passes(gpu, oracle, monkeypatch):
             continue
         assert np.array_equal(got["F"], got["0"]) and np.array_equal(got["S"], got["0"]), name
         assert np.array_equal(ranges["F"], ranges["0"]) and np.array_equal(ranges["S"], ranges["0"]), name
+        lsd[name] = (got["0"], ranges["0"], pats)
         if name in ("d1", "d1_L8_cap500"):
             ref = oracle.sais(t).astype(np.uint32) if L == 0 else oracle.truncated_sa(t, L).astype(np.uint32)
             assert np.array_equal(got["F"], ref), name
             assert np.array_equal(ranges["F"], oracle.query_batch(t, ref, L if L else 0xFFFFFFFF, pats)), name
     assert not failures, failures
     assert len(levels - {0}) >= 3, levels
-    # the int64 copy leaves the local pass with the suffixes
-    monkeypatch.delenv("SA_HIP_INITIAL_CHARS", raising=False)
+    # the large form of the local pass (sub-buckets of up to 16384 records, one workgroup of 1024 threads per CU: what a text
+    # takes whose sub-buckets outgrow 8192 at the finest level), and the split pass with published counts + look-back
     monkeypatch.delenv("SA_HIP_SPLIT_CAP", raising=False)
     monkeypatch.setenv("SA_HIP_SPLIT", "1")
     monkeypatch.setenv("SA_HIP_SPLIT_FLAGS", "1")
+    for env in ("SA_HIP_LOCAL_BIG", "SA_HIP_SPLIT_ATOMIC"):
+        monkeypatch.setenv(env, "1" if env == "SA_HIP_LOCAL_BIG" else "0")
+        for name, t, k0, L, cap, taken in runs[:3]:
+            if k0:
+                monkeypatch.setenv("SA_HIP_INITIAL_CHARS", str(k0))
+            else:
+                monkeypatch.delenv("SA_HIP_INITIAL_CHARS", raising=False)
+            with gpu.DeviceIndex(t.size, 0) as idx:
+                idx.build(t, L)
+                st = idx.build_stats()
+                assert st["split_plan"] > 0 and idx.verify() == 0, (env, name, st)
+                assert np.array_equal(idx.sa_u32(), lsd[name][0]), (env, name)
+                assert np.array_equal(idx.query_batch(lsd[name][2]), lsd[name][1]), (env, name)
+        monkeypatch.delenv(env)
+    # the int64 copy leaves the local pass with the suffixes
+    monkeypatch.delenv("SA_HIP_INITIAL_CHARS", raising=False)
     import torch
     t = runs[0][1]
     with gpu.DeviceIndex(t.size, 0) as idx:

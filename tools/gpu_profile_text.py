@@ -36,6 +36,6 @@ with _capi.DeviceIndex(t.size, 0) as idx:
         idx.build_device(idx.text_dev, t.size, L)
         ms.append(idx.build_stats()["total_ms"])
     st = idx.build_stats()
-    print("%s n=%d L=%d builds=%d: best %.2f ms median %.2f ms (%.2f Gchars/s) radix %.2f ms passes %d k0=%d rounds %d (chunk %d dbl %d) active_total %d tiny %d verify=%d" % (
+    print("%s n=%d L=%d builds=%d: best %.2f ms median %.2f ms (%.2f Gchars/s) radix %.2f ms passes %d k0=%d rounds %d (chunk %d dbl %d) active_total %d tiny %d verify=%d split rb=%d max=%d flags=%d" % (
         kind, t.size, L, builds, min(ms), sorted(ms)[len(ms) // 2], t.size / min(ms) / 1e6, st["radix_ms"], st["radix_passes"], st["initial_chars"], st["rounds"],
-        st["chunk_rounds"], st["doubling_rounds"], st["active_total"], st.get("tiny_resolved", -1), idx.verify()), flush=True)
+        st["chunk_rounds"], st["doubling_rounds"], st["active_total"], st.get("tiny_resolved", -1), idx.verify(), st["split_plan"], st["split_max"], st["lite_flags"]), flush=True)

@@ -10,9 +10,7 @@ print('$*', 'build_ms %.3f' % d['build_ms'], {k: round(v['avg_launch_ms'],3) for
 }
 for r in 1 2; do
   run SA_HIP_SPLIT_FLAGS=1
-  run SA_HIP_SPLIT_FLAGS=0
-  run SA_HIP_SPLIT_ATOMIC=0
-  run SA_HIP_SPLIT=0
+  run SA_HIP_LOCAL_BIG=1
 done
 for r in; do
   run SA_HIP_SPLIT_ITEMS=24 SA_HIP_LOCAL_BINS=11
