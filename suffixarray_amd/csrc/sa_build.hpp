@@ -1592,7 +1592,6 @@ struct Builder {
             //  this read, 0.147 ms without, and the build time is the same within the noise)
             const u64 n16 = ((1ull << q_dbits) + 1) / 4;
             if (const char* e = diag_env("SA_HIP_DIR_TOUCH")) { if (atoi(e) == 0) return 0; }
-            if (dir_by_local_pass) return 0;   // written minutes of GPU time ago no longer: the sort's last pass stored it, in one sweep per sub-bucket
             hipLaunchKernelGGL(dir_touch_kernel, dim3(stream_grid(n16, 256)), dim3(256), 0, stream, qdir.as<uint4>(), n16,
                                reinterpret_cast<u32*>(small.as<u8>() + 3588));
             return 0;
