@@ -468,6 +468,7 @@ struct TextPassArgs {
     u32 epoch;
     DeviceStatus* dstat;
     u32 incl_mask;
+    u32* cursor;            // CLAIM form: [RADIX] records of a digit placed so far (zeroed by the host)
 };
 constexpr int TEXT_HALO = 64;   // >= k0 - 1 (k0 * b <= 40)
 // positions per thread of the text-sourced top-digit pass.  24 (tiles of 12288 as in the narrow passes: 118 VGPRs, 71 KB of
@@ -486,7 +487,12 @@ __device__ __forceinline__ void shl_or_inplace(u32& acc, u32 x, int s) {
 
 // (b and k0 stay run-time values: with b = 5, k0 = 8 as compile-time constants the compiler merges a key's eight byte
 // reads into one unaligned ds_read_b64 and the pass gets slower, 4.54 vs 3.69 ms at N = 1e9.)
-template <bool FULL, int BLOCK, bool EXT>
+// CLAIM (round 4): the pass need not be stable when the three-pass plan follows (radix_split.hpp: its local pass orders by
+// (key, suffix) whatever order it finds): a tile then claims its place inside a digit with one returning global atomic per
+// non-empty digit instead of publishing its counts and looking back over its predecessors, as seg_split_kernel does.
+// RANKA (with CLAIM): the place inside the tile's digit from one returning LDS atomic per record on ONE tile-wide counter array
+// instead of the ballot-match masks (about 40 vector instructions per record less; not stable).
+template <bool FULL, int BLOCK, bool EXT, bool CLAIM = false, bool RANKA = false>
 __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 tile, const u32 chunk,
                                               const u32 tile_n, u32* s_keys, u32* s_whist, u32* s_gdelta, u32* s_wsum,
                                               u8* s_code, const u8* s_map, u16* s_ext) {
@@ -499,7 +505,7 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
     const u64 tile_base = (u64)tile * TILE;
     const u32 woff = (u32)wave * (WAVE * ITEMS) + lane;
 
-    const u32 dbase = (tid < RADIX) ? a.digit_base[chunk * RADIX + tid] : 0u;   // needed after the look-back
+    const u32 dbase = (tid < RADIX) ? a.digit_base[(CLAIM ? 0u : chunk) * RADIX + tid] : 0u;   // needed after the look-back (CLAIM: the digit's start)
 
     // 0. text -> codes in LDS: 16 bytes per thread, the halo by the first TEXT_HALO / 16 threads
     //    (the text buffer is readable for TEXT_PAD >= 16 bytes past n; a load starts below n or is skipped)
@@ -567,21 +573,36 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
 
     // 2. rank by the top digit (bits 24..31 of hi)
     u32 rd[ITEMS];
-    u32* wh = s_whist + wave * RADIX;
-    wave_rank<FULL>(hi, 24, 255u, woff, tile_n, wh, rd);
-    __syncthreads();   // also: every read of s_code is done (it becomes the digit array below)
+    u32* wh = s_whist + (RANKA ? 0 : wave * RADIX);
+    if constexpr (RANKA) {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 d = hi[j] >> 24;
+            const u32 r = atomicAdd(&s_whist[(FULL || (woff + j * WAVE) < tile_n) ? d : (u32)RADIX], 1u);   // (a slot beyond the text: the spare word of wave 1's counters)
+            rd[j] = r | (d << 16);
+        }
+        sync_lds();
+    } else {
+        wave_rank<FULL>(hi, 24, 255u, woff, tile_n, wh, rd);
+        __syncthreads();   // also: every read of s_code is done (it becomes the digit array below)
+    }
 
     // 3. tile digit counts -> aggregate -> exclusive scan over digits
-    u32 count = 0, excl = 0;
+    u32 count = 0, excl = 0, claim = 0;
     if (tid < RADIX) {
         u32 c = 0;
+        if constexpr (RANKA) { c = s_whist[tid]; }
+        else {
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
             const u32 t = s_whist[w * RADIX + tid];
             s_whist[w * RADIX + tid] = c;
             c += t;
         }
+        }
         count = c;
+        if (CLAIM) { if (c) claim = atomicAdd(&a.cursor[tid], c); }   // requested now, needed for the stores
+        else
         __hip_atomic_store(&a.status[(u64)tile * RADIX + tid],
                            pack_status(a.epoch, tile == first_tile ? FLAG_INCL : FLAG_AGG, count),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -597,8 +618,11 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
     __syncthreads();
     if (tid < RADIX) {
         for (int i = 0; i < wave; ++i) excl += s_wsum[i];
+        if constexpr (RANKA) s_whist[tid] = excl;
+        else {
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) s_whist[w * RADIX + tid] += excl;
+        }
     }
     __syncthreads();
 
@@ -618,8 +642,8 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
 
     // 5. look-back
     if (tid < RADIX) {
-        u32 prefix = 0;
-        if (tile > first_tile) {
+        u32 prefix = claim;
+        if (!CLAIM && tile > first_tile) {
             prefix = lookback_prefix(a.status, tile, first_tile, (u32)tid, a.epoch, a.dstat);
             if (((tile - first_tile) & a.incl_mask) == a.incl_mask)
                 __hip_atomic_store(&a.status[(u64)tile * RADIX + tid], pack_status(a.epoch, FLAG_INCL, prefix + count),
@@ -654,7 +678,7 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
 }
 
 // 79 VGPRs and 50 KB of LDS: three workgroups (24 waves) per CU
-template <int BLOCK, bool EXT = false>
+template <int BLOCK, bool EXT = false, bool CLAIM = false, bool RANKA = false>
 __global__ __launch_bounds__(BLOCK, (TEXT_ITEMS > 16 || EXT) ? 4 : 6) void text_top_pass_kernel(TextPassArgs a) {
     constexpr int WAVES = BLOCK / WAVE;
     constexpr u32 TILE = BLOCK * TEXT_ITEMS;
@@ -691,9 +715,9 @@ __global__ __launch_bounds__(BLOCK, (TEXT_ITEMS > 16 || EXT) ? 4 : 6) void text_
     const u32 chunk = s_chunk;
     const u64 rest = a.n - (u64)tile * TILE;
     if (rest >= (u64)TILE)
-        text_top_tile<true, BLOCK, EXT>(a, tile, chunk, TILE, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map, s_ext);
+        text_top_tile<true, BLOCK, EXT, CLAIM, RANKA>(a, tile, chunk, TILE, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map, s_ext);
     else
-        text_top_tile<false, BLOCK, EXT>(a, tile, chunk, (u32)rest, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map, s_ext);
+        text_top_tile<false, BLOCK, EXT, CLAIM, RANKA>(a, tile, chunk, (u32)rest, s_keys, s_whist, s_gdelta, s_wsum, s_code, s_map, s_ext);
 }
 
 // ---- pass 0 of the plain LSD sort straight from the text ---------------------------------------------------
@@ -939,6 +963,9 @@ struct NarrowWorkspace {
     u32* split_hist = nullptr;     // [RADIX][SPLIT_NB]
     u32* split_base = nullptr;     // [RADIX][SPLIT_NB]
     u32* split_cursor = nullptr;   // [RADIX][SPLIT_NB]: the ATOMIC form's claims
+    u32* top_cursor = nullptr;     // [RADIX]: the claims of the top-digit pass's CLAIM form
+    bool top_atomic_ranks = false; // SA_HIP_TOP_ARANKS=1: ... with LDS-atomic ranks as well
+    bool top_claims = true;        // SA_HIP_TOP_CLAIMS=0: the top-digit pass always in its stable form (published counts + look-back)
     bool split_atomic = true;      // SA_HIP_SPLIT_ATOMIC=0: the split pass with published counts and a look-back per bucket instead of claims by global atomics
                                    // (measured: 4.25 against 3.05-3.45 ms at n = 1e9, profiles/r04_split_plan_atomic_ab.log)
     u32* split_sub = nullptr;      // [(RADIX << SPLIT_BITS) + 1] sub-bucket starts | [16] largest group per level
@@ -967,9 +994,12 @@ struct NarrowWorkspace {
         SA_HIP_CHECK(hipMalloc(&split_hist, split_table_bytes()));
         SA_HIP_CHECK(hipMalloc(&split_base, split_table_bytes()));
         SA_HIP_CHECK(hipMalloc(&split_cursor, split_table_bytes()));
+        SA_HIP_CHECK(hipMalloc(&top_cursor, RADIX * sizeof(u32)));
         SA_HIP_CHECK(hipMalloc(&split_sub, (split_sub_words() + 16) * sizeof(u32)));
         SA_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host_word), 64, hipHostMallocDefault));
         if (const char* e = diag_env("SA_HIP_SPLIT")) split_enabled = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_TOP_CLAIMS")) top_claims = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_TOP_ARANKS")) top_atomic_ranks = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_LOCAL_BIG")) local_big = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_SPLIT_ATOMIC")) split_atomic = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_SPLIT_FLAGS")) split_flags = atoi(e) != 0;
@@ -998,12 +1028,13 @@ struct NarrowWorkspace {
         if (split_hist) (void)hipFree(split_hist);
         if (split_base) (void)hipFree(split_base);
         if (split_cursor) (void)hipFree(split_cursor);
+        if (top_cursor) (void)hipFree(top_cursor);
         if (split_sub) (void)hipFree(split_sub);
         if (split_status) (void)hipFree(split_status);
         if (host_word) (void)hipHostFree(host_word);
         map_dev = nullptr;
         plan = nullptr; hist = nullptr; base = nullptr; tickets = nullptr;
-        split_hist = split_base = split_sub = split_cursor = nullptr; split_status = nullptr; split_tiles = 0; host_word = nullptr;
+        split_hist = split_base = split_sub = split_cursor = top_cursor = nullptr; split_status = nullptr; split_tiles = 0; host_word = nullptr;
     }
 };
 
@@ -1091,6 +1122,26 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
     SA_HIP_CHECK(hipMemsetAsync(nw.hist, 0, NarrowWorkspace::hist_bytes(), stream));
     SA_HIP_CHECK(hipMemsetAsync(nw.tickets, 0, (size_t)NARROW_MAX_PASSES * NCHUNK * sizeof(u32), stream));
 
+    // the three-pass plan (radix_split.hpp) is considered for this sort; its passes do not need the top-digit pass to be stable,
+    // so that pass runs in its CLAIM form first -- and once more, stable, should the plan be declined (skewed text)
+    const bool try_split = nw.split_enabled && keep_narrow && ws.block == 512 && lo_bits - LOCAL_BIN_BITS >= 1;
+    const bool optimistic = try_split && src && nw.top_claims;
+    auto launch_text_top = [&](bool claim) -> int {
+        TextPassArgs t;
+        t.text = src->text; t.map = nw.map_dev; t.n = n; t.b = src->b; t.k0 = src->k0; t.begin_bit = begin_bit;
+        t.keys_out32 = reinterpret_cast<u32*>(keysB); t.ext_out16 = nullptr; t.vals_out = valsB; t.g = g; t.digit_base = ws.base();
+        t.status = ws.status; t.ticket = ws.tickets(); t.epoch = ws.epoch; t.dstat = ws.dstat; t.incl_mask = SA_INCL_MASK;
+        t.cursor = nw.top_cursor;
+        int r;
+        if (claim) SA_HIP_CHECK(hipMemsetAsync(nw.top_cursor, 0, RADIX * sizeof(u32), stream));
+        if ((r = ws.timer.start(stream, 1))) return r;
+        if (claim && nw.top_atomic_ranks) hipLaunchKernelGGL((text_top_pass_kernel<512, false, true, true>), dim3(g.tiles), dim3(512), 0, stream, t);
+        else if (claim) hipLaunchKernelGGL((text_top_pass_kernel<512, false, true>), dim3(g.tiles), dim3(512), 0, stream, t);
+        else hipLaunchKernelGGL((text_top_pass_kernel<512>), dim3(g.tiles), dim3(512), 0, stream, t);
+        if ((r = ws.timer.stop(stream, (u64)n * 9u))) return r;
+        ws.pass_records += n; ws.pass_bytes += (u64)n * 9u; ws.passes += 1;
+        return 0;
+    };
     // top digit: values generated, keys leave as their low bits -- from the text, or from the u64 key array by the
     // ordinary one-sweep pass
     {
@@ -1100,14 +1151,7 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
         }
         hipLaunchKernelGGL(radix_scan_hist_kernel, dim3(1), dim3(256), 0, stream, ws.hist(0), ws.base());
         if (src) {
-            TextPassArgs t;
-            t.text = src->text; t.map = nw.map_dev; t.n = n; t.b = src->b; t.k0 = src->k0; t.begin_bit = begin_bit;
-            t.keys_out32 = reinterpret_cast<u32*>(keysB); t.ext_out16 = nullptr; t.vals_out = valsB; t.g = g; t.digit_base = ws.base();
-            t.status = ws.status; t.ticket = ws.tickets(); t.epoch = ws.epoch; t.dstat = ws.dstat; t.incl_mask = SA_INCL_MASK;
-            if ((rc = ws.timer.start(stream, 1))) return rc;
-            hipLaunchKernelGGL((text_top_pass_kernel<512>), dim3(g.tiles), dim3(512), 0, stream, t);
-            if ((rc = ws.timer.stop(stream, (u64)n * 9u))) return rc;
-            ws.pass_records += n; ws.pass_bytes += (u64)n * 9u; ws.passes += 1;
+            if ((rc = launch_text_top(optimistic))) return rc;
         } else {
             SortPassArgs a;
             a.keys_in = keysA; a.vals_in = nullptr; a.keys_out = nullptr; a.vals_out = valsB;
@@ -1123,7 +1167,6 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
     }
     const u32 seg_tile_n = 512u * SEG_ITEMS;
     const u32 flat_max = n / seg_tile_n + 1 + RADIX;   // >= sum over buckets of ceil(size / tile)
-    const bool try_split = nw.split_enabled && keep_narrow && ws.block == 512 && lo_bits - LOCAL_BIN_BITS >= 1;
     const u32 split_tile_n = 512u * (u32)nw.split_items;   // the split pass has its own tile size: the plan is made for it first
     const u32 split_flat_max = n / split_tile_n + 1 + RADIX;
     hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(256), 0, stream, ws.hist(0), try_split ? split_tile_n : seg_tile_n, nw.plan);
@@ -1258,6 +1301,14 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
             *vals_res = valsB;
             return 0;
         }
+    }
+    if (optimistic) {   // declined: the LSD passes keep ties in the order they find them, so the top-digit pass once more, stable
+        SA_HIP_CHECK(hipMemsetAsync(ws.tickets(), 0, NCHUNK * sizeof(u32), stream));
+        if (++ws.epoch >= (1u << 30)) {
+            SA_HIP_CHECK(hipMemsetAsync(ws.status, 0, (size_t)ws.max_tiles * RADIX * sizeof(u64), stream));
+            ws.epoch = 1;
+        }
+        if ((rc = launch_text_top(false))) return rc;
     }
     if (try_split && split_tile_n != seg_tile_n)   // declined: the plan again, for the tiles of the LSD passes
         hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(256), 0, stream, ws.hist(0), seg_tile_n, nw.plan);

@@ -226,8 +226,9 @@ def test_split_plan_matches_lsd_passes(gpu, oracle, monkeypatch):
     monkeypatch.delenv("SA_HIP_SPLIT_CAP", raising=False)
     monkeypatch.setenv("SA_HIP_SPLIT", "1")
     monkeypatch.setenv("SA_HIP_SPLIT_FLAGS", "1")
-    for env in ("SA_HIP_LOCAL_BIG", "SA_HIP_SPLIT_ATOMIC"):
-        monkeypatch.setenv(env, "1" if env == "SA_HIP_LOCAL_BIG" else "0")
+    # ... and the top-digit pass in its stable form (the default with this plan: claims by global atomics), and with LDS-atomic ranks
+    for env, val in (("SA_HIP_LOCAL_BIG", "1"), ("SA_HIP_SPLIT_ATOMIC", "0"), ("SA_HIP_TOP_CLAIMS", "0"), ("SA_HIP_TOP_ARANKS", "1")):
+        monkeypatch.setenv(env, val)
         for name, t, k0, L, cap, taken in runs[:3]:
             if k0:
                 monkeypatch.setenv("SA_HIP_INITIAL_CHARS", str(k0))
