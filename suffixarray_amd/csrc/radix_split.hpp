@@ -557,8 +557,10 @@ __global__ __launch_bounds__(BLOCK, 4) void local_finish_kernel(LocalArgs a) {
     //    loop over the slots: 4.9 -> 7.5 ms at n = 1e9; with a per-slot flags body inside its sixteen copies: 6.8-7.3 ms; a second
     //    walk over the sorted keys after it: 6.2 ms).  FLAGS asks one more thing of it: is the NEXT slot's key the same?  (the
     //    neighbour comes with the same LDS instruction.)  Only then -- 0.2 % of the slots of a near-random text -- the slot looks
-    //    back as well and stages what is tied: itself when it starts the group, its successor always.  The rows of a
-    //    sub-bucket arrive in any order; lite_gather_kernel puts a row into slot order.
+    //    back as well and stages what is tied: itself when it starts the group, its successor always -- after the loop, from a
+    //    bit mask (the staging code inside the sixteen copies cost 0.8 ms).  The rows of a sub-bucket arrive in any order;
+    //    lite_gather_kernel puts a row into slot order.
+    u32 tmask = 0;   // FLAGS: bit j = the slot after item j's carries the same key
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const u32 p = (u32)j * BLOCK + tid;
@@ -569,22 +571,29 @@ __global__ __launch_bounds__(BLOCK, 4) void local_finish_kernel(LocalArgs a) {
             if (a.vals_out64) a.vals_out64[s + p] = (int64_t)(u32)x;
             if (FLAGS) {
                 const u64 xn = s_rec[p + 1];   // (s_rec[m] = ~0)
-                if ((u32)(xn >> 32) == (u32)(x >> 32) && p + 1 < m) {
-                    const bool starts = (p == 0) || ((u32)(s_rec[p - 1] >> 32) != (u32)(x >> 32));
-                    u32 at = atomicAdd(&s_na, starts ? 2u : 1u);
-                    if (starts) {
-                        atomicAdd(&s_nh, 1u);
-                        if (at < LITE_CAP) {
-                            const u64 row = (u64)blockIdx.x * LITE_CAP + at;
-                            a.lite.st_pos[row] = s + p; a.lite.st_idx[row] = (u32)x; a.lite.st_head[row] = 1;
-                        }
-                        ++at;
-                    }
-                    if (at < LITE_CAP) {
-                        const u64 row = (u64)blockIdx.x * LITE_CAP + at;
-                        a.lite.st_pos[row] = s + p + 1; a.lite.st_idx[row] = (u32)xn; a.lite.st_head[row] = 0;
-                    }
+                tmask |= ((u32)(xn >> 32) == (u32)(x >> 32) && p + 1 < m) ? (1u << j) : 0u;
+            }
+        }
+    }
+    if (FLAGS) {
+        while (tmask) {   // 3 % of the threads of a near-random text get here, with one bit
+            const u32 j = (u32)__builtin_ctz(tmask);
+            tmask &= tmask - 1u;
+            const u32 p = j * BLOCK + (u32)tid;
+            const u64 x = s_rec[p], xn = s_rec[p + 1];
+            const bool starts = (p == 0) || ((u32)(s_rec[p - 1] >> 32) != (u32)(x >> 32));
+            u32 at = atomicAdd(&s_na, starts ? 2u : 1u);
+            if (starts) {
+                atomicAdd(&s_nh, 1u);
+                if (at < LITE_CAP) {
+                    const u64 row = (u64)blockIdx.x * LITE_CAP + at;
+                    a.lite.st_pos[row] = s + p; a.lite.st_idx[row] = (u32)x; a.lite.st_head[row] = 1;
                 }
+                ++at;
+            }
+            if (at < LITE_CAP) {
+                const u64 row = (u64)blockIdx.x * LITE_CAP + at;
+                a.lite.st_pos[row] = s + p + 1; a.lite.st_idx[row] = (u32)xn; a.lite.st_head[row] = 0;
             }
         }
     }

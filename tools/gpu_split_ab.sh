@@ -9,9 +9,8 @@ print('$*', 'build_ms %.3f' % d['build_ms'], {k: round(v['avg_launch_ms'],3) for
 " || echo "$* FAILED"
 }
 for r in 1 2; do
-  run SA_HIP_TOP_CLAIMS=1
-  run SA_HIP_TOP_CLAIMS=0
-  run SA_HIP_TOP_ARANKS=1
+  run SA_HIP_SPLIT_FLAGS=1
+  run SA_HIP_SPLIT_FLAGS=0
 done
 for r in; do
   run SA_HIP_SPLIT_ITEMS=24 SA_HIP_LOCAL_BINS=11
