@@ -550,6 +550,10 @@ def run_single(args, torch, _capi, synth, dev, device):
         # byte histogram 1, top-digit histogram 1, bucket histogram 4, flags pass 4 + 1, compaction 1; the int64
         # output: 8 bytes per character inside the last sort pass (already in its pass bytes) or 12 as a pass of its own
         other = 12.0 + (0.0 if last.get("widen_fused") else 12.0)
+        if last.get("split_plan") and last.get("lite_flags") == 2:
+            # three-pass plan with the flags work inside the local pass: byte histogram 1, top-digit histogram 1, split histogram 4
+            # (no flags pass, no compaction: the directory slice and the tied slots leave with the local pass)
+            other = 6.0 + (0.0 if last.get("widen_fused") else 12.0)
         total_bytes = radix_bytes + other * N * steps
         line["whole_build"] = {"bytes_per_char_model": total_bytes / (N * steps), "achieved": total_bytes / (total_ms / 1e3) / 1e9,
                                "unit": "GB/s", "frac": total_bytes / (total_ms / 1e3) / HBM_PEAK}

@@ -564,22 +564,24 @@ __global__ __launch_bounds__(BLOCK, 4) void local_finish_kernel(LocalArgs a) {
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const u32 p = (u32)j * BLOCK + tid;
-        if ((u32)j * BLOCK < m && p < m) {
+        if ((u32)j * BLOCK < m) {   // (workgroup-uniform; a lane beyond m reads a stale word of s_rec and stores nothing)
             const u64 x = s_rec[p];
-            a.keys_out[s + p] = (u32)(x >> 32);
-            a.vals_out[s + p] = (u32)x;
-            if (a.vals_out64) a.vals_out64[s + p] = (int64_t)(u32)x;
+            const u32 k = (u32)(x >> 32);
+            if (p < m) {
+                a.keys_out[s + p] = k;
+                a.vals_out[s + p] = (u32)x;
+                if (a.vals_out64) a.vals_out64[s + p] = (int64_t)(u32)x;
+            }
             if (FLAGS) {
-                const u64 xn = s_rec[p + 1];   // (s_rec[m] = ~0)
-                tmask |= ((u32)(xn >> 32) == (u32)(x >> 32) && p + 1 < m) ? (1u << j) : 0u;
+                // the next slot's key from the next lane's register (row_shl:1 -- no LDS read in this loop); the last lane of a
+                // row of 16 sees its own key inverted, its pair is looked at after the loop
+                const u32 kn = (u32)__builtin_amdgcn_update_dpp((int)~k, (int)k, 0x101, 0xF, 0xF, false);
+                tmask |= (kn == k && p + 1 < m) ? (1u << j) : 0u;
             }
         }
     }
     if (FLAGS) {
-        while (tmask) {   // 3 % of the threads of a near-random text get here, with one bit
-            const u32 j = (u32)__builtin_ctz(tmask);
-            tmask &= tmask - 1u;
-            const u32 p = j * BLOCK + (u32)tid;
+        auto stage_pair = [&](u32 p) {   // slots p and p + 1 carry the same key
             const u64 x = s_rec[p], xn = s_rec[p + 1];
             const bool starts = (p == 0) || ((u32)(s_rec[p - 1] >> 32) != (u32)(x >> 32));
             u32 at = atomicAdd(&s_na, starts ? 2u : 1u);
@@ -595,7 +597,15 @@ __global__ __launch_bounds__(BLOCK, 4) void local_finish_kernel(LocalArgs a) {
                 const u64 row = (u64)blockIdx.x * LITE_CAP + at;
                 a.lite.st_pos[row] = s + p + 1; a.lite.st_idx[row] = (u32)xn; a.lite.st_head[row] = 0;
             }
+        };
+        while (tmask) {   // 3 % of the threads of a near-random text get here, with one bit
+            const u32 j = (u32)__builtin_ctz(tmask);
+            tmask &= tmask - 1u;
+            stage_pair(j * BLOCK + (u32)tid);
         }
+        // the pairs across a row of 16 lanes (slots 16 t + 15 | 16 t + 16)
+        for (u32 p = (u32)tid * 16u + 15u; p + 1 < m; p += (u32)BLOCK * 16u)
+            if ((u32)(s_rec[p] >> 32) == (u32)(s_rec[p + 1] >> 32)) stage_pair(p);
     }
     if (FLAGS) {
         sync_lds();
