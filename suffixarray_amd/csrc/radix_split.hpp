@@ -36,6 +36,9 @@
 
 namespace sa {
 
+#ifndef SA_ABL
+#define SA_ABL 0   // ablation mask of the FLAGS work in local_finish_kernel (tools/ only; 0 in the product)
+#endif
 constexpr int SPLIT_BITS = 10;
 constexpr int SPLIT_NB = 1 << SPLIT_BITS;       // bins of the split pass (fewer are used when rb < SPLIT_BITS)
 constexpr u32 LOCAL_CAP = 8192;                 // records of a sub-bucket the local pass holds: 512 threads x 16, 74 KB of LDS, two workgroups per CU
@@ -399,7 +402,7 @@ struct LocalArgs {
     // shares its 8 + rb key bits, so which slots are tied with a neighbour, and which directory buckets a slot owns, is
     // decided inside it: the pass over the sorted keys (4 n bytes read, 1.6 ms at n = 1e9) is not needed.
     DirArgs dir;           // the query path's bucket directory (dbits >= 8 + rb)
-    uint2* counts;         // [sub-buckets] {active slots, active heads}
+    uint2* counts;         // [sub-buckets] {active slots, active heads}, zeroed by the host
     LiteArgs lite;         // staging rows [sub-buckets][LITE_CAP] (lite.sa unused)
     int lo_shift;          // full key of a slot = (bucket << 56) | (narrow key << lo_shift)
     int rb;
@@ -427,7 +430,6 @@ __global__ __launch_bounds__(BLOCK, 4) void local_finish_kernel(LocalArgs a) {
     __shared__ __attribute__((aligned(16))) u32 s_cw[WORDS + 4];   // counts, then starts, of bins 2w | 2w + 1 << 16; [WORDS] low half: start[NB] = m
     __shared__ u32 s_wsum[BLOCK / WAVE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ u32 s_na, s_nh;   // FLAGS: active slots / active heads of the sub-bucket
     const u32 s = a.sub[blockIdx.x];
     const u32 m = a.sub[blockIdx.x + 1] - s;
     // FLAGS: the directory buckets of this sub-bucket's key prefix are [dfirst, dfirst + nd)
@@ -437,8 +439,7 @@ __global__ __launch_bounds__(BLOCK, 4) void local_finish_kernel(LocalArgs a) {
     if (FLAGS && tid == 0 && blockIdx.x == gridDim.x - 1) a.dir.dir[1u << a.dir.dbits] = a.n;   // the end marker
     if (m == 0) {
         if (FLAGS) {   // every bucket of an empty sub-bucket points at the next slot
-            for (u32 e = tid; e < nd; e += BLOCK) a.dir.dir[dfirst + e] = s;
-            if (tid == 0) a.counts[blockIdx.x] = make_uint2(0u, 0u);
+            if (!(SA_ABL & 8)) for (u32 e = tid; e < nd; e += BLOCK) a.dir.dir[dfirst + e] = s;
         }
         return;
     }
@@ -458,7 +459,6 @@ __global__ __launch_bounds__(BLOCK, 4) void local_finish_kernel(LocalArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < WPT; ++i) s_cw[WPT * tid + i] = 0;
-    if (FLAGS && tid == 0) { s_na = 0; s_nh = 0; }
     __syncthreads();
 
     // 1. load; place inside the bin from one returning LDS atomic per record
@@ -509,8 +509,8 @@ __global__ __launch_bounds__(BLOCK, 4) void local_finish_kernel(LocalArgs a) {
     const u16* s_st = reinterpret_cast<const u16*>(s_cw);   // start of bin b (little endian: the low half is the even bin)
     // FLAGS: dir[bkt] = first slot whose key's top bits are >= bkt = s + the records of the sub-bucket in lower buckets.  The bins
     // are the key bits right below the sub-bucket's and at least as fine as the directory (the host has checked g2 <= BB), so
-    // that count is the start of the bucket's first bin: the slice of the directory is the bin-start table, subsampled
-    if (FLAGS) for (u32 e = tid; e < nd; e += BLOCK) a.dir.dir[dfirst + e] = s + (u32)s_st[e << (BB - g2)];
+    // that count is the start of the bucket's first bin: the slice of the directory is the bin-start table, subsampled (written at
+    // the very end, behind the record stores: s_cw is not touched again)
 
     // 3. records -> LDS in bin order
 #pragma unroll
@@ -560,6 +560,35 @@ __global__ __launch_bounds__(BLOCK, 4) void local_finish_kernel(LocalArgs a) {
     //    back as well and stages what is tied: itself when it starts the group, its successor always -- after the loop, from a
     //    bit mask (the staging code inside the sixteen copies cost 0.8 ms).  The rows of a sub-bucket arrive in any order;
     //    lite_gather_kernel puts a row into slot order.
+    // FLAGS work that does not depend on the store loop goes BEFORE it -- whatever follows the stores keeps a finished workgroup
+    // resident (measured: the same work behind the loop, in any arrangement, cost 0.8 ms at n = 1e9)
+    auto stage_pair = [&](u32 p) {   // slots p and p + 1 carry the same key
+        const u64 x = s_rec[p], xn = s_rec[p + 1];
+        const bool starts = (p == 0) || ((u32)(s_rec[p - 1] >> 32) != (u32)(x >> 32));
+        // (the sub-bucket's {active, heads} pair lives in global memory, zeroed by the host: the few threads that get here add to
+        //  it, and the kernel needs neither a counter in LDS nor a barrier at its end)
+        u32 at = atomicAdd(&a.counts[blockIdx.x].x, starts ? 2u : 1u);
+        if (at + (starts ? 2u : 1u) > LITE_CAP) __hip_atomic_store(a.lite.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (starts) {
+            atomicAdd(&a.counts[blockIdx.x].y, 1u);
+            if (at < LITE_CAP) {
+                const u64 row = (u64)blockIdx.x * LITE_CAP + at;
+                a.lite.st_pos[row] = s + p; a.lite.st_idx[row] = (u32)x; a.lite.st_head[row] = 1;
+            }
+            ++at;
+        }
+        if (at < LITE_CAP) {
+            const u64 row = (u64)blockIdx.x * LITE_CAP + at;
+            a.lite.st_pos[row] = s + p + 1; a.lite.st_idx[row] = (u32)xn; a.lite.st_head[row] = 0;
+        }
+    };
+    if (FLAGS) {
+        if (!(SA_ABL & 1)) for (u32 e = tid; e < nd; e += BLOCK) a.dir.dir[dfirst + e] = s + (u32)s_st[e << (BB - g2)];
+        // the pairs across a row of 16 lanes (slots 16 t + 15 | 16 t + 16)
+        if (!(SA_ABL & 4))
+        for (u32 p = (u32)tid * 16u + 15u; p + 1 < m; p += (u32)BLOCK * 16u)
+            if ((u32)(s_rec[p] >> 32) == (u32)(s_rec[p + 1] >> 32)) stage_pair(p);
+    }
     u32 tmask = 0;   // FLAGS: bit j = the slot after item j's carries the same key
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -572,46 +601,19 @@ __global__ __launch_bounds__(BLOCK, 4) void local_finish_kernel(LocalArgs a) {
                 a.vals_out[s + p] = (u32)x;
                 if (a.vals_out64) a.vals_out64[s + p] = (int64_t)(u32)x;
             }
-            if (FLAGS) {
+            if (FLAGS && !(SA_ABL & 2)) {
                 // the next slot's key from the next lane's register (row_shl:1 -- no LDS read in this loop); the last lane of a
-                // row of 16 sees its own key inverted, its pair is looked at after the loop
+                // row of 16 sees its own key inverted, its pair has been looked at before the loop
                 const u32 kn = (u32)__builtin_amdgcn_update_dpp((int)~k, (int)k, 0x101, 0xF, 0xF, false);
                 tmask |= (kn == k && p + 1 < m) ? (1u << j) : 0u;
             }
         }
     }
     if (FLAGS) {
-        auto stage_pair = [&](u32 p) {   // slots p and p + 1 carry the same key
-            const u64 x = s_rec[p], xn = s_rec[p + 1];
-            const bool starts = (p == 0) || ((u32)(s_rec[p - 1] >> 32) != (u32)(x >> 32));
-            u32 at = atomicAdd(&s_na, starts ? 2u : 1u);
-            if (starts) {
-                atomicAdd(&s_nh, 1u);
-                if (at < LITE_CAP) {
-                    const u64 row = (u64)blockIdx.x * LITE_CAP + at;
-                    a.lite.st_pos[row] = s + p; a.lite.st_idx[row] = (u32)x; a.lite.st_head[row] = 1;
-                }
-                ++at;
-            }
-            if (at < LITE_CAP) {
-                const u64 row = (u64)blockIdx.x * LITE_CAP + at;
-                a.lite.st_pos[row] = s + p + 1; a.lite.st_idx[row] = (u32)xn; a.lite.st_head[row] = 0;
-            }
-        };
         while (tmask) {   // 3 % of the threads of a near-random text get here, with one bit
             const u32 j = (u32)__builtin_ctz(tmask);
             tmask &= tmask - 1u;
             stage_pair(j * BLOCK + (u32)tid);
-        }
-        // the pairs across a row of 16 lanes (slots 16 t + 15 | 16 t + 16)
-        for (u32 p = (u32)tid * 16u + 15u; p + 1 < m; p += (u32)BLOCK * 16u)
-            if ((u32)(s_rec[p] >> 32) == (u32)(s_rec[p + 1] >> 32)) stage_pair(p);
-    }
-    if (FLAGS) {
-        sync_lds();
-        if (tid == 0) {
-            a.counts[blockIdx.x] = make_uint2(s_na, s_nh);
-            if (s_na > LITE_CAP) __hip_atomic_store(a.lite.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -1465,6 +1465,7 @@ struct Builder {
         b->lite.st_head = reinterpret_cast<u8*>(b->lite.st_idx + (size_t)nsub * LITE_CAP);
         b->lite.overflow = b->totals_dev() + 2;
         SA_HIP_CHECK(hipMemsetAsync(b->lite.overflow, 0, 4, b->stream));
+        SA_HIP_CHECK(hipMemsetAsync(b->counts.p, 0, (size_t)nsub * sizeof(uint2), b->stream));   // the local pass adds to the pairs of the sub-buckets that hold ties
         b->split_dir = d;
         b->lite_tiles = nsub;
         l->dir = d;
@@ -1953,6 +1954,8 @@ struct Builder {
         stats.text_top_pass = text_pass ? 1u : 0u;
         // (a narrow sort fed from a u64 key array -- no text pass -- needs the wide buffers for that array)
         if ((rc = ensure_key_buffers(n, narrow_path && text_pass && narrow_k && fuse_directory))) return rc;
+        if (diag_env("SA_HIP_DEBUG_ADDR"))   // diagnostic: where the streams of the sort passes lie (tools/gpu_addr.sh)
+            fprintf(stderr, "[sa_hip] addr text=%p keys0=%p keys1=%p vals0=%p vals1=%p sa64=%p\n", text.p, keys0.p, keys1.p, vals0.p, vals1.p, (void*)sa64_out);
         // the plain 12-byte-record sort can take its pass 0 from the text too (no key array written and read back)
         const bool wide_text = !narrow_path && !narrow48_path && wide_text_pass && fuse_hist && radix.block == 512 && text_pass_applies(b, k0) &&
                                pl.npasses > 1 && n >= (1u << 16);
