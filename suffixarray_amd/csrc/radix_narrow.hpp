@@ -468,7 +468,8 @@ struct TextPassArgs {
     u32 epoch;
     DeviceStatus* dstat;
     u32 incl_mask;
-    u32* cursor;            // CLAIM form: [RADIX] records of a digit placed so far (zeroed by the host)
+    u32* cursor;            // CLAIM form: records of a digit placed so far (zeroed by the host): cursor[digit * cursor_stride]
+    u32 cursor_stride;      // 64 words by default: every digit's counter in a 256-byte line of its own (SA_HIP_CURSOR_PAD=0: 1)
 };
 constexpr int TEXT_HALO = 64;   // >= k0 - 1 (k0 * b <= 40)
 // positions per thread of the text-sourced top-digit pass.  24 (tiles of 12288 as in the narrow passes: 118 VGPRs, 71 KB of
@@ -601,7 +602,7 @@ __device__ __forceinline__ void text_top_tile(const TextPassArgs& a, const u32 t
         }
         }
         count = c;
-        if (CLAIM) { if (c) claim = atomicAdd(&a.cursor[tid], c); }   // requested now, needed for the stores
+        if (CLAIM) { if (c) claim = atomicAdd(&a.cursor[(size_t)tid * a.cursor_stride], c); }   // requested now, needed for the stores
         else
         __hip_atomic_store(&a.status[(u64)tile * RADIX + tid],
                            pack_status(a.epoch, tile == first_tile ? FLAG_INCL : FLAG_AGG, count),
@@ -964,6 +965,8 @@ struct NarrowWorkspace {
     u32* split_base = nullptr;     // [RADIX][SPLIT_NB]
     u32* split_cursor = nullptr;   // [RADIX][SPLIT_NB]: the ATOMIC form's claims
     u32* top_cursor = nullptr;     // [RADIX]: the claims of the top-digit pass's CLAIM form
+    bool cursor_pad = true;        // SA_HIP_CURSOR_PAD=0: the 256 claim counters of the top-digit pass packed into 1 KB (measured on a slow host: 4.1-4.2 against 3.5-3.8 ms)
+    bool split_cursor_t = false;   // SA_HIP_SPLIT_CURSOR_T=1: the split pass's counters as [bin][bucket] (a tile's claims 1 KB apart; measured no better)
     bool top_atomic_ranks = false; // SA_HIP_TOP_ARANKS=1: ... with LDS-atomic ranks as well
     bool top_claims = true;        // SA_HIP_TOP_CLAIMS=0: the top-digit pass always in its stable form (published counts + look-back)
     bool split_atomic = true;      // SA_HIP_SPLIT_ATOMIC=0: the split pass with published counts and a look-back per bucket instead of claims by global atomics
@@ -994,10 +997,12 @@ struct NarrowWorkspace {
         SA_HIP_CHECK(hipMalloc(&split_hist, split_table_bytes()));
         SA_HIP_CHECK(hipMalloc(&split_base, split_table_bytes()));
         SA_HIP_CHECK(hipMalloc(&split_cursor, split_table_bytes()));
-        SA_HIP_CHECK(hipMalloc(&top_cursor, RADIX * sizeof(u32)));
+        SA_HIP_CHECK(hipMalloc(&top_cursor, (size_t)RADIX * 64 * sizeof(u32)));
         SA_HIP_CHECK(hipMalloc(&split_sub, (split_sub_words() + 16) * sizeof(u32)));
         SA_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host_word), 64, hipHostMallocDefault));
         if (const char* e = diag_env("SA_HIP_SPLIT")) split_enabled = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_CURSOR_PAD")) cursor_pad = atoi(e) != 0;
+        if (const char* e = diag_env("SA_HIP_SPLIT_CURSOR_T")) split_cursor_t = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_TOP_CLAIMS")) top_claims = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_TOP_ARANKS")) top_atomic_ranks = atoi(e) != 0;
         if (const char* e = diag_env("SA_HIP_LOCAL_BIG")) local_big = atoi(e) != 0;
@@ -1119,7 +1124,6 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
     const int lo_bits = 56 - begin_bit;                       // 1 .. 32
     const int np = (lo_bits + RADIX_BITS - 1) / RADIX_BITS;   // narrow passes, 1 .. 4
     const SortGeom g = make_geom(n, src ? TEXT_TILE : ws.tile());
-    SA_HIP_CHECK(hipMemsetAsync(nw.hist, 0, NarrowWorkspace::hist_bytes(), stream));
     SA_HIP_CHECK(hipMemsetAsync(nw.tickets, 0, (size_t)NARROW_MAX_PASSES * NCHUNK * sizeof(u32), stream));
 
     // the three-pass plan (radix_split.hpp) is considered for this sort; its passes do not need the top-digit pass to be stable,
@@ -1131,9 +1135,9 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
         t.text = src->text; t.map = nw.map_dev; t.n = n; t.b = src->b; t.k0 = src->k0; t.begin_bit = begin_bit;
         t.keys_out32 = reinterpret_cast<u32*>(keysB); t.ext_out16 = nullptr; t.vals_out = valsB; t.g = g; t.digit_base = ws.base();
         t.status = ws.status; t.ticket = ws.tickets(); t.epoch = ws.epoch; t.dstat = ws.dstat; t.incl_mask = SA_INCL_MASK;
-        t.cursor = nw.top_cursor;
+        t.cursor = nw.top_cursor; t.cursor_stride = nw.cursor_pad ? 64u : 1u;
         int r;
-        if (claim) SA_HIP_CHECK(hipMemsetAsync(nw.top_cursor, 0, RADIX * sizeof(u32), stream));
+        if (claim) SA_HIP_CHECK(hipMemsetAsync(nw.top_cursor, 0, (size_t)RADIX * 64 * sizeof(u32), stream));
         if ((r = ws.timer.start(stream, 1))) return r;
         if (claim && nw.top_atomic_ranks) hipLaunchKernelGGL((text_top_pass_kernel<512, false, true, true>), dim3(g.tiles), dim3(512), 0, stream, t);
         else if (claim) hipLaunchKernelGGL((text_top_pass_kernel<512, false, true>), dim3(g.tiles), dim3(512), 0, stream, t);
@@ -1224,6 +1228,7 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
             a.keys_out = reinterpret_cast<u32*>(keysA); a.vals_out = valsA;
             a.plan = nw.plan; a.shift = dshift; a.mask = dmask; a.digit_base = nw.split_base; a.status = nw.split_status;
             a.ticket = nw.tickets; a.epoch = ws.epoch; a.dstat = ws.dstat; a.incl_mask = SA_INCL_MASK; a.cursor = nw.split_cursor;
+            a.cur_bs = nw.split_cursor_t ? 1u : (u32)SPLIT_NB; a.cur_ds = nw.split_cursor_t ? (u32)RADIX : 1u;
             if ((rc = ws.timer.start(stream, 2))) return rc;
             if (nw.split_atomic) {
                 if (nw.split_items == 32) hipLaunchKernelGGL((seg_split_kernel<512, 32, true>), dim3(split_flat_max), dim3(512), 0, stream, a);
@@ -1312,7 +1317,8 @@ inline int radix_sort_narrow(RadixWorkspace& ws, NarrowWorkspace& nw, hipStream_
     }
     if (try_split && split_tile_n != seg_tile_n)   // declined: the plan again, for the tiles of the LSD passes
         hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(256), 0, stream, ws.hist(0), seg_tile_n, nw.plan);
-    // histogram of the first narrow digit per bucket
+    // histogram of the first narrow digit per bucket (the LSD passes' histograms are zeroed here: the three-pass plan has no use for them)
+    SA_HIP_CHECK(hipMemsetAsync(nw.hist, 0, NarrowWorkspace::hist_bytes(), stream));
     {
         const u32 tpb = 4;
         const u32 mask0 = (1u << ((np == 1) ? lo_bits : RADIX_BITS)) - 1u;

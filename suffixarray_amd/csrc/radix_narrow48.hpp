@@ -274,7 +274,7 @@ inline int radix_sort_narrow48(RadixWorkspace& ws, NarrowWorkspace& nw, hipStrea
         TextPassArgs t;
         t.text = src.text; t.map = nw.map_dev; t.n = n; t.b = src.b; t.k0 = src.k0; t.begin_bit = begin_bit;
         t.keys_out32 = k32_of(keysB); t.ext_out16 = k16_of(keysB); t.vals_out = valsB; t.g = g; t.digit_base = ws.base();
-        t.status = ws.status; t.ticket = ws.tickets(); t.epoch = ws.epoch; t.dstat = ws.dstat; t.incl_mask = SA_INCL_MASK; t.cursor = nullptr;
+        t.status = ws.status; t.ticket = ws.tickets(); t.epoch = ws.epoch; t.dstat = ws.dstat; t.incl_mask = SA_INCL_MASK; t.cursor = nullptr; t.cursor_stride = 1;
         if ((rc = ws.timer.start(stream, 1))) return rc;
         hipLaunchKernelGGL((text_top_pass_kernel<512, true>), dim3(g.tiles), dim3(512), 0, stream, t);
         if ((rc = ws.timer.stop(stream, (u64)n * 11u))) return rc;

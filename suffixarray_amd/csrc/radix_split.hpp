@@ -116,13 +116,20 @@ __global__ __launch_bounds__(SPLIT_NB) void split_levels_kernel(const u32* __res
     s_p[d + 1] = incl;
     if (d == 0) s_p[0] = 0;
     __syncthreads();
-    for (int k = 0; k <= hb; ++k) {
+    __shared__ u32 s_lv[SPLIT_BITS + 1][SPLIT_NB / WAVE];   // per level, the waves' maxima: ONE global atomic per level and bucket
+    for (int k = 0; k <= hb; ++k) {                          // (one per level and wave: 45 000 atomics on 11 words, 80 us)
         const int g = hb - k;   // log2 of the fine bins per group
         u32 v = 0;
         if (d < (1 << k)) v = s_p[(d + 1) << g] - s_p[d << g];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const u32 t = __shfl_down(v, o); v = t > v ? t : v; }
-        if (lane == 0 && v) atomicMax(&levels[k], v);
+        if (lane == 0) s_lv[k][w] = v;
+    }
+    __syncthreads();
+    if (d <= hb) {
+        u32 v = 0;
+        for (int i = 0; i < SPLIT_NB / WAVE; ++i) v = s_lv[d][i] > v ? s_lv[d][i] : v;
+        if (v) atomicMax(&levels[d], v);
     }
 }
 
@@ -225,7 +232,9 @@ struct SplitPassArgs {
     u32 epoch;
     DeviceStatus* dstat;
     u32 incl_mask;
-    u32* cursor;           // ATOMIC form: [RADIX buckets][SPLIT_NB] records placed so far (zeroed by the host)
+    u32* cursor;           // ATOMIC form: records placed so far per (bucket, bin), zeroed by the host: cursor[bucket * cur_bs + bin * cur_ds]
+    u32 cur_bs, cur_ds;    // ([bucket][bin]: SPLIT_NB, 1; SA_HIP_SPLIT_CURSOR_T=1: [bin][bucket] -- 1, RADIX -- so that the claims of a tile lie 1 KB
+                           //  apart instead of in 3 KB of one bucket's row: measured no better, profiles/r04_claim_counters_layout.log)
 };
 
 // ATOMIC: a tile claims its place in a bin with one returning global atomic per non-empty bin instead of publishing its counts
@@ -263,9 +272,9 @@ __device__ __forceinline__ void split_tile(const SplitPassArgs& a, const u32 fla
     const uint2 c = *reinterpret_cast<const uint2*>(s_cnt + 2 * tid);
     u32 claim0 = 0, claim1 = 0;
     if (ATOMIC) {   // requested now, needed for the stores
-        u32* cur = a.cursor + (size_t)bucket * SPLIT_NB + 2 * tid;
+        u32* cur = a.cursor + (size_t)bucket * a.cur_bs + (size_t)(2 * tid) * a.cur_ds;
         if (c.x) claim0 = atomicAdd(cur, c.x);
-        if (c.y) claim1 = atomicAdd(cur + 1, c.y);
+        if (c.y) claim1 = atomicAdd(cur + a.cur_ds, c.y);
     } else {
         const u64 fl = (flat == first_flat) ? FLAG_INCL : FLAG_AGG;
         __hip_atomic_store(&a.status[(u64)flat * SPLIT_NB + 2 * tid], pack_status(a.epoch, fl, c.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

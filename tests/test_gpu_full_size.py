@@ -134,6 +134,48 @@ def test_config3_n1e9_properties(gpu, oracle):
             assert bytes(t[sa[nxt]:sa[nxt] + m]) > p
 
 
+def test_d1_n1p3e9_large_local_form_verified(gpu):
+    """Beyond the headline size the sub-buckets of the three-pass plan outgrow 8192 records at the finest level (D1 at n = 1.3e9:
+    10 294): the plan then takes the large form of its local pass (sub-buckets of up to 16 384 records, one workgroup of 1024
+    threads per CU) instead of falling back to five passes.  Size-independent properties: the plan taken, the suffix
+    array verified on the device (unique => bit-exact), a 64-bit build's int64 copy equal to the u32 array, hits of a query batch
+    carry their pattern."""
+    import torch
+    from suffixarray_amd import synth
+    n, q, m = 1_300_000_000, 100_000, 16
+    t = synth.d1_uniform27(n)
+    buf, off = synth.query_batch(t, q, m)
+    with gpu.DeviceIndex(n, 0) as idx:
+        idx.build(t)
+        out = torch.empty(n, dtype=torch.int64, device="cuda:0")
+        idx.build_device64(idx.text_dev, n, out.data_ptr(), 0)
+        idx.sync()
+        st = idx.build_stats()
+        assert st["split_plan"] == 10 and 8192 < st["split_max"] <= 16384 and st["radix_passes"] == 3 and st["widen_fused"] == 1, st
+        assert idx.verify() == 0, st
+        got = idx.query_batch((buf, off))
+        sa = idx.sa_u32()
+    for lo in range(0, n, 1 << 27):
+        hi = min(n, lo + (1 << 27))
+        assert np.array_equal(out[lo:hi].cpu().numpy(), sa[lo:hi].astype(np.int64))
+    del out
+    pats = buf.reshape(q, m)
+    rng = np.random.default_rng(4)
+    hits = 0
+    for i in rng.integers(0, q, 2000):
+        f, s2 = int(got["first"][i]), int(got["second"][i])
+        p = pats[i].tobytes()
+        if f == 0xFFFFFFFF or s2 < f:
+            continue
+        hits += 1
+        assert bytes(t[sa[f]:sa[f] + m]) == p and bytes(t[sa[s2]:sa[s2] + m]) == p
+        if f > 0:
+            assert bytes(t[sa[f - 1]:sa[f - 1] + m]) < p
+        if s2 + 1 < n:
+            assert bytes(t[sa[s2 + 1]:sa[s2 + 1] + m]) > p
+    assert hits > 200
+
+
 def test_d2_words_n1e9_properties(gpu, oracle):
     """SURVEY 8(d)'s realistic text at the headline size: D2 words, N = 1e9 -- the 10-byte-record sort, the in-LDS group
     finisher and the global rounds on ~5e8 tied suffixes (D1 needs none of them).  Size-independent properties: the suffix array
