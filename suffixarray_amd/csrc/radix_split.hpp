@@ -6,29 +6,37 @@
 // for an MSD continuation:
 //
 //   pass              reads              writes                                   bytes / record
-//   top digit         text               u32 narrow key, u32 suffix               1 + 8         (text_top_pass_kernel, unchanged)
-//   histogram         u32 key            hist[bucket][top rb bits of the key]     4             (split_hist_kernel)
-//   split             u32 key, u32 val   the same, grouped by those rb <= 10 bits 8 + 8         (seg_split_kernel)
-//   local finish      u32 key, u32 val   sorted u32 key, u32 suffix (+ int64)     8 + 8 (+ 8)   (local_finish_kernel)
+//   top digit         text               u32 narrow key, u32 suffix               1 + 8         (text_top_pass_kernel, in its CLAIM form)
+//   histogram         u32 key            hist[bucket][next 10 key bits]           4             (split_hist_kernel)
+//   split             u32 key, u32 val   the same, grouped by the next rb <= 10   8 + 8         (seg_split_kernel)
+//   local finish      u32 key, u32 val   sorted u32 key, u32 suffix (+ int64),    8 + 8 (+ 8)   (local_finish_kernel)
+//                                        directory slice, tied slots
 //
 // After the split pass a SUB-BUCKET -- the records that share the top digit and the next rb key bits, 256 << rb of them --
 // is contiguous and, when the text is as even as the plan assumes, holds at most LOCAL_CAP = 8192 records: one workgroup
 // takes it into LDS whole and orders it completely by the remaining key bits (ties by suffix index, which is what a stable
-// LSD sort from the identity leaves).  D1 at n = 1e9: 137 781 sub-buckets of <= 7 526 + 5 sigma records.
+// LSD sort from the identity leaves).  D1 at n = 1e9: 137 781 sub-buckets of <= 7 955 records.
 //
 //   * The split pass need not be stable (the local pass orders by (key, suffix) whatever order it finds), so it ranks
 //     with one returning LDS atomic per record on ONE tile-wide counter array -- no per-wave histograms, which at 1024 bins
-//     would not fit beside the tile.  Geometry, tickets and the per-bucket look-back chains are seg_onesweep_kernel's;
-//     a thread owns two adjacent bins in the count / scan / look-back phases.
-//   * The local pass: bin = the next LOCAL_BIN_BITS = 11 key bits; one returning LDS atomic per record gives its place in the
-//     bin, a scan over the 2048 counters the bin starts; the records go to LDS as u64 (key << 32 | suffix) in bin order, and a
-//     record's final place is its bin's start + the number of records of the bin that compare smaller (a handful: 3.7 on
-//     average at n = 1e9).  A bin with many members only costs time (members^2 comparisons), never correctness.
+//     would not fit beside the tile -- and a tile CLAIMS its place inside a bucket's bin with one returning global atomic
+//     per non-empty bin: no published counts, no look-back, nothing waits for another workgroup (ATOMIC; the look-back form,
+//     two adjacent bins per thread, is kept for A/B: 4.25 against 3.05-3.45 ms at n = 1e9).  Geometry and tickets are
+//     seg_onesweep_kernel's, with a plan of its own (tiles of 14 336 records).
+//   * The local pass: bin = the next 12 key bits, 4096 counters of 16 bits packed two per LDS word; one returning LDS atomic
+//     per record gives its place in the bin, a scan the bin starts; the records go to LDS as u64 (key << 32 | suffix) in bin
+//     order, and a record's final place is its bin's start + the number of records of the bin that compare smaller (1.8
+//     members on average at n = 1e9, two per step).  A bin with many members only costs time (members^2 comparisons), never
+//     correctness.  A large form (1024 threads, sub-buckets of <= 16 384 records, one workgroup per CU) takes texts whose
+//     sub-buckets outgrow 8192 at the finest level.
+//   * FLAGS: the build's first flags pass is folded into the local pass -- the slice of the query directory that belongs to a
+//     sub-bucket is its bin-start table, subsampled; tied slots are found in the store loop (the next slot's key from the next
+//     lane's register) and staged per sub-bucket for lite_gather_kernel.
 //   * Whether the plan applies, and with how many bits rb, is decided on the device's numbers: the histogram is taken over
 //     hb = 10 key bits, split_levels_kernel gives the largest group for every rb <= hb, and the host -- the one
 //     synchronisation this plan adds -- takes the smallest rb whose groups all fit LOCAL_CAP (D1: rb = 3 at n = 4.5e6,
-//     10 at n = 1e9); when none does the sort continues as radix_narrow.hpp's LSD passes (skewed text: the histogram
-//     pass is then the price of finding out).
+//     10 at n = 1e9), else LOCAL_CAP_BIG; when none does the sort continues as radix_narrow.hpp's LSD passes (skewed text:
+//     the histogram pass, and a second, stable run of the top-digit pass, are then the price of finding out).
 //
 // Replaces, by function only, the same libsais stages as radix_sort.hpp; no shared code or structure.
 #pragma once
