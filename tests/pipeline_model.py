@@ -123,3 +123,82 @@ def build_sa_model(text, max_suffix_length=0, chunk_rounds_before_doubling=2, k0
     if stats is not None:
         stats.update(dict(sigma=sigma, b=b, k0=k0, rounds=rounds))
     return sa
+
+
+# ---- the three-pass plan of the narrow sort (csrc/radix_split.hpp): host logic + what its two passes must leave ----
+
+def split_levels(keys, lo_bits, hb):
+    """split_hist_kernel + split_levels_kernel: keys = top digit (8 bits) above lo_bits narrow bits; the largest group per
+    level k = 0..hb when the records of a bucket are grouped by the top k of the narrow key's first hb bits."""
+    fine = (keys >> np.uint64(lo_bits - hb)).astype(np.int64)   # (bucket << hb) | fine bin
+    hist = np.bincount(fine, minlength=256 << hb)
+    return [int(hist.reshape(-1, 1 << (hb - k)).sum(axis=1).max()) for k in range(hb + 1)]
+
+
+def choose_split_level(levels, lo_bits, cap=8192, cap_big=16384):
+    """radix_sort_narrow's rule: the SMALLEST level whose groups all fit the local pass, its large form when none fits the
+    small one (needs 12 key bits below the sub-bucket's), None: the plan is declined (LSD passes).  -> (rb, big)"""
+    hb = len(levels) - 1
+    for k in range(1, hb + 1):
+        if levels[k] <= cap:
+            return k, False
+    for k in range(1, hb + 1):
+        if levels[k] <= cap_big and lo_bits - k >= 12:
+            return k, True
+    return None, False
+
+
+def three_pass_model(keys, lo_bits, dbits, cap=8192, cap_big=16384, seed=0):
+    """What the plan must leave for (key, suffix) records with suffix = position: the order of a stable sort, the query
+    directory and the staged tied slots -- derived the way the kernels derive them: the split pass groups the records of a
+    bucket by rb key bits in ANY order (here: shuffled), the local pass orders a sub-bucket by (key, suffix), reads the
+    sub-bucket's directory slice off its bin starts and finds the tied slots from neighbouring keys INSIDE the sub-bucket.
+    keys: uint64, top digit in bits [lo_bits, lo_bits + 8).  -> None (declined) or dict."""
+    n = keys.size
+    hb = min(10, lo_bits - 11)
+    if hb < 1:
+        return None
+    levels = split_levels(keys, lo_bits, hb)
+    rb, big = choose_split_level(levels, lo_bits, cap, cap_big)
+    if rb is None:
+        return None
+    bb = 12 if (big or lo_bits - rb >= 12) else 11
+    g2 = dbits - 8 - rb
+    if g2 < 0 or g2 > bb or dbits - 8 > lo_bits:
+        return None   # (the fused flags work is declined; not modelled)
+    rng = np.random.default_rng(seed)
+    sub = (keys >> np.uint64(lo_bits - rb)).astype(np.int64)          # sub-bucket = (bucket << rb) | group
+    nsub = 256 << rb
+    counts = np.bincount(sub, minlength=nsub)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    # split pass: any order inside a sub-bucket
+    shuffled = rng.permutation(n)
+    order = shuffled[np.argsort(sub[shuffled], kind="stable")]
+    out_keys = np.empty(n, np.uint64)
+    out_sa = np.empty(n, np.int64)
+    directory = np.empty((1 << dbits) + 1, np.int64)
+    directory[1 << dbits] = n
+    staged = []
+    for s_i in range(nsub):
+        lo, hi = starts[s_i], starts[s_i + 1]
+        nd = 1 << g2
+        if lo == hi:
+            directory[s_i << g2:(s_i + 1) << g2] = lo
+            continue
+        idx = order[lo:hi]
+        k = keys[idx]
+        local = np.lexsort((idx, k))                      # the local pass: (key, suffix)
+        idx, k = idx[local], k[local]
+        out_keys[lo:hi], out_sa[lo:hi] = k, idx
+        # bins: the bb key bits below the sub-bucket's; the directory slice is the bin-start table, subsampled
+        rest = lo_bits - rb
+        bins = ((k >> np.uint64(rest - bb)) & np.uint64((1 << bb) - 1)).astype(np.int64)
+        bin_start = np.concatenate([[0], np.cumsum(np.bincount(bins, minlength=1 << bb))])
+        directory[s_i << g2:(s_i + 1) << g2] = lo + bin_start[(np.arange(nd) << (bb - g2))]
+        # tied slots: slot p stages itself when it starts a group and its successor always (pairs inside the sub-bucket only)
+        same_next = np.flatnonzero(k[1:] == k[:-1])
+        for p in same_next:
+            if p == 0 or k[p - 1] != k[p]:
+                staged.append((lo + p, True))
+            staged.append((lo + p + 1, False))
+    return {"rb": rb, "big": big, "levels": levels, "keys": out_keys, "sa": out_sa, "dir": directory, "staged": sorted(staged)}

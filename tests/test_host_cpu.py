@@ -8,7 +8,7 @@ import pytest
 
 import cases
 from conftest import GOLDEN
-from pipeline_model import build_sa_model
+from pipeline_model import build_sa_model, three_pass_model, choose_split_level
 from test_oracle import check_truncated_order
 
 
@@ -207,6 +207,46 @@ def test_pipeline_model_truncated(oracle):
             got = build_sa_model(t, max_suffix_length=L)
             assert np.array_equal(got, oracle.truncated_sa(t, L)), (name, L)
             check_truncated_order(t, got, L)
+
+
+def test_three_pass_plan_model():
+    """The host logic of the three-pass plan (csrc/radix_split.hpp) and the identities its local pass rests on, in numpy: the
+    level rule (smallest level that fits, then the large form, else declined), records grouped in ANY order and ordered by
+    (key, suffix) per sub-bucket = the stable sort; the directory slice of a sub-bucket = its bin-start table subsampled = the
+    directory by binary search; the slots staged from inside the sub-buckets = the slots whose key equals a neighbour's."""
+    rng = np.random.default_rng(21)
+    assert choose_split_level([10 ** 6, 9000, 8192, 4000], 32) == (2, False)
+    assert choose_split_level([10 ** 6, 20000, 16000, 9000], 32) == (2, True)
+    assert choose_split_level([10 ** 6, 20000, 16000, 9000], 13) == (None, False)      # (no 12 key bits below the sub-bucket)
+    assert choose_split_level([10 ** 6, 10 ** 5, 10 ** 5, 10 ** 5], 32) == (None, False)
+    for n, sigma, k0, cap, dbits in ((60000, 27, 6, 64, 19), (60000, 27, 5, 300, 17), (50000, 4, 12, 40, 19), (40000, 27, 6, 16, 19)):
+        b = 1
+        while (1 << b) < sigma + 1:
+            b += 1
+        codes = rng.integers(1, sigma + 1, n + k0).astype(np.uint64)
+        codes[n:] = 0
+        key = np.zeros(n, np.uint64)
+        for j in range(k0):
+            key = (key << np.uint64(b)) | codes[np.arange(n) + j]
+        lo_bits = b * k0 - 8
+        m = three_pass_model(key, lo_bits, dbits, cap=cap, cap_big=2 * cap, seed=n)
+        assert m is not None and m["levels"][m["rb"]] <= (2 * cap if m["big"] else cap), (n, sigma, k0)
+        assert m["rb"] == 1 or m["levels"][m["rb"] - 1] > cap
+        order = np.argsort(key, kind="stable")
+        assert np.array_equal(m["sa"], order) and np.array_equal(m["keys"], key[order])
+        top = (key[order] >> np.uint64(b * k0 - dbits)).astype(np.int64)
+        assert np.array_equal(m["dir"][:-1], np.searchsorted(top, np.arange(1 << dbits), side="left")) and m["dir"][-1] == n
+        ks = key[order]
+        eq_prev = np.concatenate([[False], ks[1:] == ks[:-1]])
+        eq_next = np.concatenate([ks[1:] == ks[:-1], [False]])
+        exp = sorted((int(p), bool(not eq_prev[p])) for p in np.flatnonzero(eq_prev | eq_next))
+        assert m["staged"] == exp, (n, sigma, k0)
+    # skew: one symbol nine times in ten -- no level fits, the plan is declined
+    key = np.zeros(40000, np.uint64)
+    codes = rng.choice(np.array([1, 2, 3], np.uint64), 40000 + 16, p=[0.9, 0.05, 0.05])
+    for j in range(16):
+        key = (key << np.uint64(2)) | codes[np.arange(40000) + j]
+    assert three_pass_model(key, 24, 14, cap=64, cap_big=128) is None
 
 
 def test_csv_native_matches_python_reference(tmp_path, capi):
