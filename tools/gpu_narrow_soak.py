@@ -46,8 +46,9 @@ for c in range(cases):
     used = res["text"][2]["pass_launches"][2] + res["text"][2]["pass_launches"][3]
     ok = same and all(res[m][1] == 0 for m in res)
     bad += not ok
-    print("case %2d sigma %3d b %d k0 %2d L %2d n %8d narrow launches %d text_pass %d narrow_k %d rounds %2d -> %s" % (
+    print("case %2d sigma %3d b %d k0 %2d L %2d n %8d narrow launches %d text_pass %d narrow_k %d rounds %2d split rb %2d / %2d max %6d flags %d -> %s" % (
         c, sigma, b, res["text"][2]["initial_chars"], L, n, used, res["text"][2]["text_top_pass"], res["text"][2]["narrow_k"],
-        res["text"][2]["rounds"], "ok" if ok else "MISMATCH"), flush=True)
+        res["text"][2]["rounds"], res["text"][2]["split_plan"], res["keys"][2]["split_plan"], res["text"][2]["split_max"], res["text"][2]["lite_flags"],
+        "ok" if ok else "MISMATCH"), flush=True)
 print("FAILED %d" % bad if bad else "ALL OK")
 sys.exit(1 if bad else 0)
