@@ -37,8 +37,10 @@ struct PinnedRing {
     hipEvent_t ev[SLABS] = {};
     hipStream_t copy_stream = nullptr;                 // the down leg runs beside the index's own stream
     bool ready = false;
+    int device = -1;                                   // the device that was current when copy_stream was created
     int init() {
         if (ready) return 0;
+        SA_HIP_CHECK(hipGetDevice(&device));
         for (int i = 0; i < SLABS; ++i) {   // (a call that failed half way is completed by the next one: nothing is allocated twice)
             if (!slab[i]) SA_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&slab[i]), SLAB_BYTES, hipHostMallocDefault));
             if (!ev[i]) SA_HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
@@ -134,6 +136,50 @@ inline int ring_download(PinnedRing& r, int device, const u32* sa_dev, OUT* out,
     work(0);
     for (auto& t : th) t.join();
     if (err) return fail(SA_HIP_EHIP, "ring_download: device-to-host copy failed");
+    return 0;
+}
+
+// src_dev[0..bytes) -> consume(piece, byte offset, byte length) for consecutive pieces of `piece_bytes` (<= SLAB_BYTES; the
+// caller picks a multiple of its record size so that no record straddles two pieces).  Same pipeline as ring_download: the
+// DMA of piece k + SLABS is issued by the worker that has consumed piece k; consume() runs on up to 16 worker threads at once,
+// on disjoint pieces, and must only write what belongs to its piece.  The caller has synchronised the stream that produced
+// src_dev.  (The batched record retrieval, sa_hip_index_query_rows_batch: Q x k row ids come down as u32 and are widened
+// into the caller's uint64[Q][k] -- its first-touch page faults spread over the workers instead of one thread.)
+template <typename FN>
+inline int ring_download_pieces(PinnedRing& r, int device, const u8* src_dev, size_t bytes, size_t piece_bytes, FN consume) {
+    if (bytes == 0) return 0;
+    if (piece_bytes == 0 || piece_bytes > PinnedRing::SLAB_BYTES) return fail(SA_HIP_EINVAL, "ring_download_pieces: piece size");
+    const size_t npiece = (bytes + piece_bytes - 1) / piece_bytes;
+    unsigned W = (unsigned)std::min<size_t>(std::min<size_t>(host_workers(), PinnedRing::SLABS), npiece);
+    while (PinnedRing::SLABS % W) --W;
+    std::atomic<int> err{0};
+    auto issue = [&](size_t k) -> bool {
+        const int s = (int)(k % PinnedRing::SLABS);
+        const size_t off = k * piece_bytes;
+        const size_t len = std::min(piece_bytes, bytes - off);
+        return hipMemcpyAsync(r.slab[s], src_dev + off, len, hipMemcpyDeviceToHost, r.copy_stream) == hipSuccess &&
+               hipEventRecord(r.ev[s], r.copy_stream) == hipSuccess;
+    };
+    for (size_t k = 0; k < npiece && k < (size_t)PinnedRing::SLABS; ++k)
+        if (!issue(k)) return fail(SA_HIP_EHIP, "ring_download_pieces: device-to-host copy failed");
+    auto work = [&](unsigned w) {
+        if (hipSetDevice(device) != hipSuccess) { err = 1; return; }
+        for (size_t k = w; k < npiece && !err; k += W) {
+            const int s = (int)(k % PinnedRing::SLABS);
+            const size_t off = k * piece_bytes;
+            const size_t len = std::min(piece_bytes, bytes - off);
+            if (hipEventSynchronize(r.ev[s]) != hipSuccess) { err = 1; return; }
+            consume(static_cast<const u8*>(r.slab[s]), off, len);
+            if (k + PinnedRing::SLABS < npiece && !issue(k + PinnedRing::SLABS)) { err = 1; return; }
+        }
+    };
+    std::vector<std::thread> th;
+    try {
+        for (unsigned w = 1; w < W; ++w) th.emplace_back(work, w);
+    } catch (...) { err = 1; }
+    work(0);
+    for (auto& t : th) t.join();
+    if (err) return fail(SA_HIP_EHIP, "ring_download_pieces: device-to-host copy failed");
     return 0;
 }
 

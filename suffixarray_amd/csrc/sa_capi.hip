@@ -246,6 +246,17 @@ struct TempIndex {
     ~TempIndex() { if (idx) sa_hip_index_destroy(idx); }
 };
 
+// The process-level workspace of the libsais-call-compatible wrappers (further down): a cached index handle and the ring of
+// pinned slabs for both legs over PCIe.  The ring also carries the large host legs of sa_hip_index_query_rows_batch (under
+// `mu`; lock order: a caller's own idx->mu first, then g_oneshot.mu -- the wrappers take g_oneshot.mu and then the mutex of
+// the CACHED handle, which no caller ever holds).
+struct OneShot {
+    std::mutex mu;
+    sa_hip_index* idx = nullptr;
+    PinnedRing ring;
+    sa_hip_call_breakdown last{};
+} g_oneshot;
+
 }  // namespace
 
 extern "C" {
@@ -1088,6 +1099,10 @@ int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t 
     return 0;
 }
 
+// (batches whose Q x k row ids take less than this go down by one plain copy; SA_HIP_ROWS_RING=0: always -- A/B, tests)
+static constexpr size_t ROWS_RING_MIN_BYTES = 32u << 20;
+static bool rows_ring_off() { const char* e = diag_env("SA_HIP_ROWS_RING"); return e && e[0] == '0'; }
+
 int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_t* offsets, uint64_t Q, uint32_t k,
                                   uint64_t* row_ids, uint32_t* counts, sa_hip_pair_u32* ranges) {
     if (!idx || (Q && (!offsets || !counts || (!row_ids && k)))) return fail(SA_HIP_EINVAL, "sa_hip_index_query_rows_batch: NULL argument");
@@ -1122,14 +1137,31 @@ int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, co
     if ((rc = idx->q_pat.ensure((size_t)total + 64))) return rc;
     if ((rc = idx->q_off.ensure((size_t)(Q + 1) * 8))) return rc;
     if ((rc = idx->q_out.ensure((size_t)Q * sizeof(sa_hip_pair_u32)))) return rc;
-    if (total) SA_HIP_CHECK(hipMemcpyAsync(idx->q_pat.p, patterns, total, hipMemcpyHostToDevice, idx->stream));
+    const bool device_rows = k && k <= ROWS_K_MAX && !host_rows_forced();
+    // A large batch moves its host legs through the process's ring of pinned slabs (host_io.hpp): patterns and offsets up, counts,
+    // ranges and the Q x k row ids down as u32, widened into the caller's uint64[Q][k] by the ring's worker threads while the
+    // next slabs arrive -- instead of one pageable copy into a Q x k vector (allocated and page-faulted per call) and one
+    // thread widening it (1e7 patterns, k = 16: 353 -> see profiles/r04_n_rows_batch.log).  Same bytes, same results.
+    std::unique_lock<std::mutex> ring_lock;
+    PinnedRing* ring = nullptr;
+    if (device_rows && (size_t)Q * k * 4 >= ROWS_RING_MIN_BYTES && !rows_ring_off()) {
+        ring_lock = std::unique_lock<std::mutex>(g_oneshot.mu);
+        if (!g_oneshot.ring.ready && (rc = g_oneshot.ring.init())) return rc;
+        if (g_oneshot.ring.device == idx->device) ring = &g_oneshot.ring;
+        else ring_lock.unlock();   // (the ring's copy stream lives on another device: the plain copies below)
+    }
+    if (ring) {
+        if ((rc = ring_upload(*ring, idx->stream, idx->device, idx->q_pat.p, patterns, (size_t)total))) return rc;
+        if ((rc = ring_upload(*ring, idx->stream, idx->device, idx->q_off.p, reinterpret_cast<const u8*>(offsets), (size_t)(Q + 1) * 8))) return rc;
+    } else {
+        if (total) SA_HIP_CHECK(hipMemcpyAsync(idx->q_pat.p, patterns, total, hipMemcpyHostToDevice, idx->stream));
+        SA_HIP_CHECK(hipMemcpyAsync(idx->q_off.p, offsets, (size_t)(Q + 1) * 8, hipMemcpyHostToDevice, idx->stream));
+    }
     SA_HIP_CHECK(hipMemsetAsync(idx->q_pat.as<u8>() + total, 0, 64, idx->stream));
-    SA_HIP_CHECK(hipMemcpyAsync(idx->q_off.p, offsets, (size_t)(Q + 1) * 8, hipMemcpyHostToDevice, idx->stream));
     if ((rc = launch_query(idx, idx->q_pat.as<u8>(), idx->q_off.as<u64>(), Q, idx->q_out.as<sa_hip_pair_u32>()))) return rc;
     try {
         std::vector<sa_hip_pair_u32> rg_host;
-        const bool device_rows = k && k <= ROWS_K_MAX && !host_rows_forced();
-        if (ranges || !device_rows) {
+        if (!ring && (ranges || !device_rows)) {
             rg_host.resize(Q);
             SA_HIP_CHECK(hipMemcpyAsync(rg_host.data(), idx->q_out.p, (size_t)Q * sizeof(sa_hip_pair_u32), hipMemcpyDeviceToHost, idx->stream));
         }
@@ -1144,6 +1176,25 @@ int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, co
             a.out_rows = idx->r_rows.as<u32>(); a.out_counts = idx->r_counts.as<u32>();
             launch_rows(idx->stream, a);
             SA_HIP_CHECK(hipGetLastError());
+            if (ring) {
+                SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+                if ((rc = ring_download<u32>(*ring, idx->device, idx->r_counts.as<u32>(), counts, (size_t)Q))) return rc;
+                if (ranges && (rc = ring_download<u32>(*ring, idx->device, idx->q_out.as<u32>(), reinterpret_cast<u32*>(ranges), (size_t)Q * 2))) return rc;
+                const size_t per_q = (size_t)k * 4;                                        // k <= ROWS_K_MAX: at most 16 KB
+                const size_t piece = (PinnedRing::SLAB_BYTES / per_q) * per_q;             // whole queries per piece
+                rc = ring_download_pieces(*ring, idx->device, idx->r_rows.as<u8>(), (size_t)Q * per_q, piece,
+                                          [&](const u8* p, size_t off, size_t len) {
+                                              const u32* in = reinterpret_cast<const u32*>(p);
+                                              const u64 q0 = off / per_q, nq = len / per_q;
+                                              for (u64 j = 0; j < nq; ++j) {
+                                                  const u32 c = counts[q0 + j];
+                                                  u64* o = row_ids + (q0 + j) * k_in;
+                                                  const u32* r = in + j * k;
+                                                  for (u32 i = 0; i < c; ++i) o[i] = r[i];
+                                              }
+                                          });
+                return rc;
+            }
             std::vector<u32> rows32((size_t)Q * k);
             SA_HIP_CHECK(hipMemcpyAsync(counts, idx->r_counts.p, (size_t)Q * 4, hipMemcpyDeviceToHost, idx->stream));
             SA_HIP_CHECK(hipMemcpyAsync(rows32.data(), idx->r_rows.p, (size_t)Q * k * 4, hipMemcpyDeviceToHost, idx->stream));
@@ -1571,13 +1622,6 @@ int sa_hip_read_suffix_array(sa_hip_SuffixArray_struct* s, const char* sa_filena
 
 extern "C++" {
 namespace {
-struct OneShot {
-    std::mutex mu;
-    sa_hip_index* idx = nullptr;
-    PinnedRing ring;
-    sa_hip_call_breakdown last{};
-} g_oneshot;
-
 double ms_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -1610,6 +1654,7 @@ int oneshot_build(const uint8_t* T, uint64_t n, uint32_t L, OUT* out, FREQ* freq
     sa_hip_index* idx = g.idx;
     std::lock_guard<std::mutex> ilock(idx->mu);
     if ((rc = set_device(idx->device))) return rc;
+    if (g.ring.ready && g.ring.device != idx->device) g.ring.destroy();   // (its copy stream belongs to another device: a rows batch made it there)
     if ((rc = g.ring.init())) return rc;
     bd.workspace_ms = ms_since(t0);
     t0 = std::chrono::steady_clock::now();

@@ -439,6 +439,50 @@ def test_device_rows_equal_host_rows(gpu, monkeypatch):
         assert [r.tolist() for r in rows] == [[0, 1], [1], [], [0, 1]] or [sorted(r.tolist()) for r in rows] == [[0, 1], [1], [], [0, 1]]
 
 
+def test_large_rows_batch_through_the_pinned_ring(gpu, monkeypatch):
+    """sa_hip_index_query_rows_batch on a batch whose Q x k row ids exceed 32 MiB: the host legs go through the ring of pinned
+    slabs (host_io.hpp: ring_upload / ring_download / ring_download_pieces -- worker threads widen the u32 ids of the pieces that
+    have arrived into the caller's uint64[Q][k]) and must hand back exactly what the plain copies (SA_HIP_ROWS_RING=0) do:
+    counts, ranges and every live row id; Q and k chosen so that pieces end inside the batch and k * 4 does not divide a slab.
+    A sample of the queries is checked against the one-query call (same contract as engine.c:1326-1390 per element)."""
+    from csv_ingest import extract_column
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "c.csv")
+        gpu.synth_csv(path, 200_000, 12)
+        col = extract_column(path, "company_name")
+    text = np.frombuffer(col.text, dtype=np.uint8)
+    starts = np.asarray(col.text_row_starts, dtype=np.uint64)
+    rng = np.random.default_rng(8)
+    Q, k = 2_000_003, 13
+    pos = rng.integers(0, text.size - 12, Q).astype(np.int64)
+    lens = rng.integers(1, 9, Q).astype(np.int64)          # short substrings of the column: most hit several rows, some cross a row end
+    off = np.zeros(Q + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    idxs = np.repeat(pos - off[:-1].astype(np.int64), lens) + np.arange(int(off[-1]), dtype=np.int64)
+    buf = np.ascontiguousarray(text[idxs])
+    miss = rng.random(Q) < 0.2                              # a fifth of the patterns get a byte that never occurs: misses
+    buf[off[:-1][miss].astype(np.int64)] = 1
+    with gpu.DeviceIndex(text.size, 0) as idx:
+        idx.build(text, 32)
+        idx.set_rows(starts)
+        monkeypatch.setenv("SA_HIP_ROWS_RING", "0")
+        (rows0, cnt0), rg0 = idx.query_rows_batch_raw((buf, off), k)
+        monkeypatch.delenv("SA_HIP_ROWS_RING")
+        (rows1, cnt1), rg1 = idx.query_rows_batch_raw((buf, off), k)
+        (rows2, cnt2), rg2 = idx.query_rows_batch_raw((buf, off), k)      # the ring a second time (slabs and events reused)
+        assert np.array_equal(cnt0, cnt1) and np.array_equal(cnt0, cnt2)
+        assert np.array_equal(rg0, rg1) and np.array_equal(rg0, rg2)
+        live = np.arange(k)[None, :] < cnt0[:, None]
+        assert np.array_equal(rows0[live], rows1[live]) and np.array_equal(rows0[live], rows2[live])
+        assert int(cnt0.max()) == k and 0.1 < float((cnt0 == 0).mean()) < 0.5
+        for q in rng.integers(0, Q, 40):
+            p = bytes(buf[int(off[q]):int(off[q + 1])])
+            one, rg = idx.query_rows(p, k)
+            assert np.array_equal(one, rows1[q, :cnt1[q]]), (q, p)
+            assert (int(rg[0]), int(rg[1])) == (int(rg1[q]["first"]), int(rg1[q]["second"])), (q, p)
+
+
 def test_api_edge_cases(gpu):
     lib = gpu.lib()
     import ctypes as C
