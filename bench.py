@@ -867,8 +867,13 @@ def run_sharded_rows(args, torch, dist, synth, rank, world, dev, text, idx, sear
     q_buf, q_off = slice_pats
     ql = q_off.size - 1
 
+    # the result arrays of this rank's slice are the caller's and are kept from step to step, as a serving loop keeps them
+    # (a fresh uint64[Q][k] per call costs ~60 ms of map / unmap work per step at Q = 1e7, k = 16: profiles/r04_n_rows_lanes.log)
+    out = (np.empty((max(ql, 1), max(k, 1)), dtype=np.uint64), np.zeros(max(ql, 1), dtype=np.uint32),
+           np.zeros(max(ql, 1), dtype=[("first", "<u4"), ("second", "<u4")]))
+
     def step():
-        rows, ranges = searcher.query_rows_batch_raw((q_buf, q_off), k)
+        rows, ranges = searcher.query_rows_batch_raw((q_buf, q_off), k, out=out)
         c = torch.tensor([float(ql), float(rows[1].sum()), float((rows[1] > 0).sum())], dtype=torch.float64, device=dev)
         dist.all_reduce(c)
         return rows, ranges, c

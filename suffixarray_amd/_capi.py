@@ -534,15 +534,25 @@ class DeviceIndex:
                                                           rows.ctypes.data, counts.ctypes.data, ranges.ctypes.data))
         return [rows[i, :counts[i]].copy() for i in range(q)], ranges[:q]
 
-    def query_rows_batch_raw(self, patterns, k):
-        """query_rows_batch without the per-query Python list: ((row_ids uint64[Q, k], counts uint32[Q]), ranges)."""
+    def query_rows_batch_raw(self, patterns, k, out=None):
+        """query_rows_batch without the per-query Python list: ((row_ids uint64[Q, k], counts uint32[Q]), ranges).
+        out: (rows, counts, ranges) of an earlier call with the same Q and k, to be overwritten -- the C entry point fills
+        caller-provided arrays (as engine.c:1326 does), and a loop that answers batch after batch keeps its arrays instead of
+        mapping and unmapping Q x k x 8 bytes per call (1.28 GB at Q = 1e7, k = 16: ~60 ms of page-table work per step)."""
         buf, off = patterns if isinstance(patterns, tuple) else pack_patterns(patterns)
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         q = off.size - 1
-        rows = np.empty((max(q, 1), max(k, 1)), dtype=np.uint64)
-        counts = np.zeros(max(q, 1), dtype=np.uint32)
-        ranges = np.zeros(max(q, 1), dtype=PAIR_DTYPE)
+        if out is not None:
+            rows, counts, ranges = out
+            if (rows.shape != (max(q, 1), max(k, 1)) or rows.dtype != np.uint64 or counts.shape != (max(q, 1),) or counts.dtype != np.uint32
+                    or ranges.shape != (max(q, 1),) or ranges.dtype != PAIR_DTYPE
+                    or not (rows.flags.c_contiguous and counts.flags.c_contiguous and ranges.flags.c_contiguous)):
+                raise ValueError("query_rows_batch_raw: `out` does not fit this batch")
+        else:
+            rows = np.empty((max(q, 1), max(k, 1)), dtype=np.uint64)
+            counts = np.zeros(max(q, 1), dtype=np.uint32)
+            ranges = np.zeros(max(q, 1), dtype=PAIR_DTYPE)
         if q:
             check(self._lib.sa_hip_index_query_rows_batch(self._h, buf.ctypes.data if buf.size else None, off.ctypes.data, q, k,
                                                           rows.ctypes.data, counts.ctypes.data, ranges.ctypes.data))

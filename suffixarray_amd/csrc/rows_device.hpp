@@ -11,6 +11,12 @@
 //     new rows, in hit order: ballot prefix over the chunk -> out_rows[query][have ...]
 // until k distinct rows are collected or the range ends -- exactly the rows, in exactly the order, that
 // distinct_rows() returns (tests compare the two).  k <= ROWS_K_MAX; larger k ("all rows") stays on the host path.
+//
+// A workgroup per query keeps ~1000 queries in flight on the chip, each behind a chain of ~26 dependent probes: a batch of
+// 1e7 patterns over the N = 1e9 text (27 % hit, nearly all exactly once) spent 42 ms there.  In a batch, ranges of at most
+// ROWS_LANE_MAX hits -- misses included -- are therefore answered by ONE LANE each first (rows_lane_kernel: 64 independent
+// probe chains per wave; the rows seen so far sit in registers), and only the longer ranges, appended to a list by wave-
+// aggregated atomics, go through the workgroup form.  Same rows in the same order by construction (first-hit order).
 #pragma once
 #include "common.hpp"
 
@@ -21,6 +27,8 @@ constexpr int ROWS_COARSE_SHIFT = 8;
 constexpr u32 ROWS_SLOTS_SMALL = 4096;    // k <= 1536: 32 KB of LDS
 constexpr u32 ROWS_K_SMALL = 1536;
 constexpr u32 ROWS_SLOTS_LARGE = 16384;   // k <= 4096: 128 KB of LDS (one workgroup per CU)
+constexpr u32 ROWS_LANE_MAX = 4;          // hits of a range that one lane answers on its own (batches)
+constexpr u64 ROWS_LANE_MIN_BATCH = 4096; // smaller batches go straight to the workgroup form (one launch)
 
 struct RowsArgs {
     const u32* sa;
@@ -33,7 +41,72 @@ struct RowsArgs {
     u32 k;                           // 1 .. ROWS_K_MAX (and <= what SLOTS allows)
     u32* out_rows;                   // [q][k]
     u32* out_counts;                 // [q]
+    const u32* pending = nullptr;    // rows_kernel: the queries left for it ([*n_pending], any order), or nullptr: all q
+    const u32* n_pending = nullptr;
 };
+
+// the row that holds text position pos: the last row whose start is <= pos (row_starts[0] = 0)
+__device__ __forceinline__ u32 row_of_pos(const RowsArgs& a, const u64 pos) {
+    u64 lo = 0, hi = a.num_rows;             // first row whose start is > pos
+    if (a.coarse) {                          // (uniform) narrow [lo, hi) to one block of 256 rows through the small table
+        u64 cl = 0, ch = a.coarse_n;         // first block whose first row starts > pos (>= 1: coarse[0] = 0 <= pos)
+        while (cl < ch) {
+            const u64 mid = (cl + ch) >> 1;
+            if (a.coarse[mid] <= pos) cl = mid + 1; else ch = mid;
+        }
+        lo = (cl - 1) << ROWS_COARSE_SHIFT;  // row_starts[lo] <= pos
+        const u64 end = cl << ROWS_COARSE_SHIFT;
+        hi = end < a.num_rows ? end : a.num_rows;   // cl < coarse_n: row_starts[end] > pos
+    }
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (a.row_starts[mid] <= pos) lo = mid + 1; else hi = mid;
+    }
+    return (u32)(lo - 1);
+}
+
+__device__ __forceinline__ u32 hits_of_range(const sa_hip_pair_u32 rg) {   // miss: second = first - 1, or both UINT32_MAX
+    return (rg.first != 0xFFFFFFFFu && (u32)(rg.second - rg.first + 1u) != 0u) ? rg.second - rg.first + 1u : 0u;
+}
+
+// One lane per query: ranges of <= ROWS_LANE_MAX hits are answered completely (distinct rows in first-hit order, at most k),
+// the others are appended to pending[] (their out_counts entry is written by rows_kernel).
+__global__ __launch_bounds__(256) void rows_lane_kernel(RowsArgs a, u32* __restrict__ pending, u32* __restrict__ n_pending) {
+    const u64 qi = (u64)blockIdx.x * 256 + threadIdx.x;
+    bool big = false;
+    if (qi < a.q) {
+        const sa_hip_pair_u32 rg = a.ranges[qi];
+        const u32 count = hits_of_range(rg);
+        if (count <= ROWS_LANE_MAX) {
+            u32 r[ROWS_LANE_MAX];
+            u32 have = 0;
+            for (u32 i = 0; i < count && have < a.k; ++i) {
+                const u32 row = row_of_pos(a, a.sa[(u64)rg.first + i]);
+                bool seen = false;
+#pragma unroll
+                for (u32 j = 0; j < ROWS_LANE_MAX; ++j) seen |= (j < have && r[j] == row);
+                if (!seen) {
+#pragma unroll
+                    for (u32 j = 0; j < ROWS_LANE_MAX; ++j) if (j == have) r[j] = row;   // (no dynamic register indexing)
+                    a.out_rows[qi * a.k + have] = row;
+                    ++have;
+                }
+            }
+            a.out_counts[qi] = have;
+        } else {
+            big = true;
+        }
+    }
+    const u64 m = __ballot(big);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        u32 base = 0;
+        if (lane == leader) base = atomicAdd(n_pending, (u32)__popcll(m));
+        base = __shfl(base, leader);
+        if (big) pending[base + (u32)__popcll(m & lanemask_lt())] = (u32)qi;
+    }
+}
 
 // the rows of ONE range (all 256 threads of the workgroup; s_tab: SLOTS entries, s_wcnt: 4)
 template <u32 SLOTS>
@@ -42,8 +115,7 @@ __device__ __forceinline__ void rows_of_range(const RowsArgs& a, const u64 qi, c
     constexpr int SHIFT = 32 - (SLOTS == 4096 ? 12 : 14);
     static_assert(SLOTS == 4096 || SLOTS == 16384, "table sizes");
     {
-        u32 count = 0;
-        if (rg.first != 0xFFFFFFFFu && (u32)(rg.second - rg.first + 1u) != 0u) count = rg.second - rg.first + 1u;   // miss: second = first - 1
+        const u32 count = hits_of_range(rg);
         for (u32 i = tid; i < SLOTS; i += 256) s_tab[i] = 0ull;
         __syncthreads();
         u32 have = 0;
@@ -52,23 +124,7 @@ __device__ __forceinline__ void rows_of_range(const RowsArgs& a, const u64 qi, c
             const u32 i = (u32)(base + (u64)tid);
             u32 row = 0, slot = 0;
             if (valid) {
-                const u64 pos = a.sa[(u64)rg.first + i];
-                u64 lo = 0, hi = a.num_rows;             // first row whose start is > pos
-                if (a.coarse) {                          // (uniform) narrow [lo, hi) to one block of 256 rows through the small table
-                    u64 cl = 0, ch = a.coarse_n;         // first block whose first row starts > pos (>= 1: coarse[0] = 0 <= pos)
-                    while (cl < ch) {
-                        const u64 mid = (cl + ch) >> 1;
-                        if (a.coarse[mid] <= pos) cl = mid + 1; else ch = mid;
-                    }
-                    lo = (cl - 1) << ROWS_COARSE_SHIFT;  // row_starts[lo] <= pos
-                    const u64 end = cl << ROWS_COARSE_SHIFT;
-                    hi = end < a.num_rows ? end : a.num_rows;   // cl < coarse_n: row_starts[end] > pos
-                }
-                while (lo < hi) {
-                    const u64 mid = (lo + hi) >> 1;
-                    if (a.row_starts[mid] <= pos) lo = mid + 1; else hi = mid;
-                }
-                row = (u32)(lo - 1);                     // row_starts[0] = 0 <= pos
+                row = row_of_pos(a, a.sa[(u64)rg.first + i]);
                 const unsigned long long key = (unsigned long long)(row + 1u) << 32;
                 slot = (row * 0x9E3779B1u) >> SHIFT;
                 while (true) {
@@ -102,7 +158,11 @@ template <u32 SLOTS>
 __global__ __launch_bounds__(256) void rows_kernel(RowsArgs a) {
     __shared__ unsigned long long s_tab[SLOTS];   // (row + 1) << 32 | index of the row's first hit; 0 = empty
     __shared__ u32 s_wcnt[4];
-    for (u64 qi = blockIdx.x; qi < a.q; qi += gridDim.x) rows_of_range<SLOTS>(a, qi, a.ranges[qi], s_tab, s_wcnt);
+    const u64 nq = a.pending ? (u64)*a.n_pending : a.q;
+    for (u64 i = blockIdx.x; i < nq; i += gridDim.x) {
+        const u64 qi = a.pending ? (u64)a.pending[i] : i;
+        rows_of_range<SLOTS>(a, qi, a.ranges[qi], s_tab, s_wcnt);
+    }
 }
 
 // ONE query, one launch (the latency path of get_matching_records_file): thread 0 searches, the workgroup then collects the rows
@@ -125,8 +185,17 @@ __global__ __launch_bounds__(256) void query_rows_one_kernel(QueryArgs qa, CodeM
     rows_of_range<SLOTS>(ra, 0, s_rg, s_tab, s_wcnt);
 }
 
-inline void launch_rows(hipStream_t stream, const RowsArgs& a) {
+// pend: device buffer of a.q + 1 u32 (the list of the queries the lane kernel leaves + its length), or nullptr / a small
+// batch: every query goes through the workgroup form.
+inline void launch_rows(hipStream_t stream, RowsArgs a, u32* pend = nullptr) {
     if (a.q == 0) return;
+    if (pend && a.q >= ROWS_LANE_MIN_BATCH && a.q <= 0xFFFFFFFFull) {
+        u32* n_pending = pend + a.q;
+        (void)hipMemsetAsync(n_pending, 0, 4, stream);
+        hipLaunchKernelGGL(rows_lane_kernel, dim3((u32)((a.q + 255) / 256)), dim3(256), 0, stream, a, pend, n_pending);
+        a.pending = pend;
+        a.n_pending = n_pending;
+    }
     u64 g = a.q;
     if (a.k <= ROWS_K_SMALL) {
         if (g > 256u * 8u) g = 256u * 8u;

@@ -49,6 +49,7 @@ struct sa_hip_index {
     DevBuf rows_coarse;            // every 256th entry of it (stays cached)
     u64 rows_coarse_n = 0;
     DevBuf r_rows, r_counts;       // results of the rows kernel (batched form)
+    DevBuf r_pending;              // ... and the list of the queries its lane kernel leaves to the workgroup form (+ its length)
     std::unique_ptr<HostIndex> host;   // set: the opt-in no-GPU path of config 1 (host_index.hpp); nothing below touches HIP then
     bool receiving = false;        // sa_hip_index_replica_reserve .. _commit: the buffers are being filled by the caller
     bool k2_auto = true;           // sa_hip_index_deep_keys: large batches build the second-level keys on their way
@@ -315,7 +316,7 @@ void sa_hip_index_destroy(sa_hip_index* idx) {
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     idx->b.destroy();
     idx->q_pat.release(); idx->q_off.release(); idx->q_out.release(); idx->widen.release();
-    idx->rows_dev.release(); idx->rows_coarse.release(); idx->r_rows.release(); idx->r_counts.release();
+    idx->rows_dev.release(); idx->rows_coarse.release(); idx->r_rows.release(); idx->r_counts.release(); idx->r_pending.release();
     idx->qc_hist.release(); idx->qc_off.release(); idx->qc_part.release(); idx->qc_tmp.release();
     if (idx->qh_host) (void)hipHostFree(idx->qh_host);
     for (int i = 0; i < sa_hip_index::QRING; ++i)
@@ -1101,6 +1102,7 @@ int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t 
 
 // (batches whose Q x k row ids take less than this go down by one plain copy; SA_HIP_ROWS_RING=0: always -- A/B, tests)
 static constexpr size_t ROWS_RING_MIN_BYTES = 32u << 20;
+static bool rows_lanes_off() { const char* e = diag_env("SA_HIP_ROWS_LANES"); return e && e[0] == '0'; }   // A/B, tests: every query through the workgroup form
 static bool rows_ring_off() { const char* e = diag_env("SA_HIP_ROWS_RING"); return e && e[0] == '0'; }
 
 int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_t* offsets, uint64_t Q, uint32_t k,
@@ -1169,12 +1171,14 @@ int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, co
             // ... ONE rows launch for all the hits -> rows, one copy back: no per-query synchronisation
             if ((rc = idx->r_rows.ensure((size_t)Q * k * 4))) return rc;
             if ((rc = idx->r_counts.ensure((size_t)Q * 4))) return rc;
+            const bool lanes = Q >= ROWS_LANE_MIN_BATCH && !rows_lanes_off();
+            if (lanes && (rc = idx->r_pending.ensure(((size_t)Q + 1) * 4))) return rc;
             RowsArgs a;
             a.sa = idx->b.sa; a.ranges = idx->q_out.as<sa_hip_pair_u32>(); a.q = Q;
             a.row_starts = idx->rows_dev.as<u64>(); a.num_rows = idx->row_starts.size(); a.k = k;
             a.coarse = (idx->rows_coarse_n > 1) ? idx->rows_coarse.as<u64>() : nullptr; a.coarse_n = idx->rows_coarse_n;
             a.out_rows = idx->r_rows.as<u32>(); a.out_counts = idx->r_counts.as<u32>();
-            launch_rows(idx->stream, a);
+            launch_rows(idx->stream, a, lanes ? idx->r_pending.as<u32>() : nullptr);
             SA_HIP_CHECK(hipGetLastError());
             if (ring) {
                 SA_HIP_CHECK(hipStreamSynchronize(idx->stream));

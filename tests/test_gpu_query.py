@@ -476,6 +476,26 @@ def test_large_rows_batch_through_the_pinned_ring(gpu, monkeypatch):
         live = np.arange(k)[None, :] < cnt0[:, None]
         assert np.array_equal(rows0[live], rows1[live]) and np.array_equal(rows0[live], rows2[live])
         assert int(cnt0.max()) == k and 0.1 < float((cnt0 == 0).mean()) < 0.5
+        # ranges of at most 4 hits (misses included) are answered by one lane each, the rest by a workgroup per query
+        # (rows_device.hpp: rows_lane_kernel + the pending list): against every query through the workgroup form ...
+        monkeypatch.setenv("SA_HIP_ROWS_LANES", "0")
+        (rows3, cnt3), rg3 = idx.query_rows_batch_raw((buf, off), k)
+        monkeypatch.delenv("SA_HIP_ROWS_LANES")
+        assert np.array_equal(cnt0, cnt3) and np.array_equal(rg0, rg3) and np.array_equal(rows0[live], rows3[live])
+        hits = ((rg0["second"].astype(np.int64) - rg0["first"].astype(np.int64) + 1) & 0xFFFFFFFF) * (rg0["first"] != 0xFFFFFFFF)
+        assert (hits == 0).sum() > 1000 and ((hits >= 1) & (hits <= 4)).sum() > 1000 and (hits > 4).sum() > 1000, np.bincount(np.minimum(hits, 6))
+        # ... and a slice of the batch against the host path (records.hpp: distinct_rows), for several k
+        sl = slice(1_000_000, 1_030_000)
+        sub = (buf[int(off[sl.start]):int(off[sl.stop])], (off[sl.start:sl.stop + 1] - off[sl.start]).astype(np.uint64))
+        for kk in (1, 2, 3, 13, 40):
+            monkeypatch.setenv("SA_HIP_HOST_ROWS", "1")
+            (hr, hc), hrg = idx.query_rows_batch_raw(sub, kk)
+            monkeypatch.delenv("SA_HIP_HOST_ROWS")
+            (dr, dc), drg = idx.query_rows_batch_raw(sub, kk)
+            lv = np.arange(kk)[None, :] < hc[:, None]
+            assert np.array_equal(hc, dc) and np.array_equal(hrg, drg) and np.array_equal(hr[lv], dr[lv]), kk
+            if kk == k:
+                assert np.array_equal(dc, cnt1[sl]) and np.array_equal(dr[lv], rows1[sl][lv])
         for q in rng.integers(0, Q, 40):
             p = bytes(buf[int(off[q]):int(off[q + 1])])
             one, rg = idx.query_rows(p, k)
