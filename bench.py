@@ -258,7 +258,7 @@ def config5_csv(_capi, rows=50_000_000, budget_s=12.0):
         col = idx.text()
         out["names_batch_1e6"] = names_batch(idx, col, rng)
         # a batch large enough for the clustering of round 4 (from 2^20 patterns on: answered in the order of the patterns' first characters)
-        out["names_batch_8e6"] = names_batch(idx, col, rng, q=8_000_000)
+        out["names_batch_8e6"] = names_batch(idx, col, rng, q=8_000_000, rows_k=0)
         s.close()
         del s, idx
         out["documents_5M"] = documents_protocol(col, rng)
@@ -271,7 +271,7 @@ def config5_csv(_capi, rows=50_000_000, budget_s=12.0):
             pass
 
 
-def names_batch(idx, col, rng, q=1_000_000):
+def names_batch(idx, col, rng, q=1_000_000, rows_k=16):
     """The reference's real query load -- names that occur (tests/test.py:103-127) -- as ONE batch: q rows sampled from the
     column, searched by one launch (sa_hip_query_batch: host patterns in, ranges out); kernel time from the library's events."""
     ends = np.flatnonzero(col == 10)
@@ -300,7 +300,23 @@ def names_batch(idx, col, rng, q=1_000_000):
     best, res = run(4)
     cnt = ((res["second"].astype(np.int64) - res["first"].astype(np.int64) + 1) & 0xFFFFFFFF)
     cnt[res["first"] == 0xFFFFFFFF] = 0
-    return {"queries": int(a.size), "mean_pattern_len": float(lens.mean()), "kernel_ms": best, "queries_per_s": a.size / (best / 1e3),
+    rows_out = None
+    if rows_k:
+        # ... and the same batch all the way to row ids (what query_records_batch needs: sa_hip_index_query_rows_batch, host patterns
+        # in, up to rows_k distinct row ids per name out; ranges of <= 4 hits by one lane each, longer ones by a workgroup each)
+        keep_arrays = (np.empty((a.size, rows_k), dtype=np.uint64), np.zeros(a.size, dtype=np.uint32),
+                       np.zeros(a.size, dtype=[("first", "<u4"), ("second", "<u4")]))
+        call_ms = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            (rw, rc_), rr = idx.query_rows_batch_raw((buf, off), rows_k, out=keep_arrays)
+            call_ms.append((time.perf_counter() - t0) * 1e3)
+        rows_out = {"k": rows_k, "call_ms": min(call_ms[1:]), "queries_per_s": a.size / (min(call_ms[1:]) / 1e3),
+                    "mean_rows": float(rc_.mean()), "ranges_of_at_most_4_hits": float((cnt <= 4).mean()),
+                    "same_ranges_as_the_search": bool(np.array_equal(rr["first"], res["first"]) and np.array_equal(rr["second"], res["second"])),
+                    "counts_consistent": bool(np.array_equal(rc_ > 0, cnt > 0) and int(rc_.max()) <= rows_k),
+                    "note": "host clock around the call: patterns up, search, rows kernels, counts + ranges + row ids down into the caller's arrays"}
+    return {"queries": int(a.size), "rows_batch": rows_out, "mean_pattern_len": float(lens.mean()), "kernel_ms": best, "queries_per_s": a.size / (best / 1e3),
             "hit_rate": float((cnt > 0).mean()), "mean_hits": float(cnt.mean()), "median_hits": float(np.median(cnt)),
             "deep_keys": {"built": bool(has), "build_ms_host_clock": k2_build_ms, "same_ranges": bool(np.array_equal(res, plain)),
                           "without": {"kernel_ms": plain_ms, "queries_per_s": a.size / (plain_ms / 1e3)}},
