@@ -1185,7 +1185,9 @@ int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, co
                 if ((rc = ring_download<u32>(*ring, idx->device, idx->r_counts.as<u32>(), counts, (size_t)Q))) return rc;
                 if (ranges && (rc = ring_download<u32>(*ring, idx->device, idx->q_out.as<u32>(), reinterpret_cast<u32*>(ranges), (size_t)Q * 2))) return rc;
                 const size_t per_q = (size_t)k * 4;                                        // k <= ROWS_K_MAX: at most 16 KB
-                const size_t piece = (PinnedRing::SLAB_BYTES / per_q) * per_q;             // whole queries per piece
+                // whole queries per piece; about 32 pieces (1 MB .. one slab) so that a mid-size batch still spreads over all workers
+                const size_t target = std::min<size_t>(PinnedRing::SLAB_BYTES, std::max<size_t>((size_t)1 << 20, (size_t)Q * per_q / 32));
+                const size_t piece = std::max<size_t>(per_q, (target / per_q) * per_q);
                 rc = ring_download_pieces(*ring, idx->device, idx->r_rows.as<u8>(), (size_t)Q * per_q, piece,
                                           [&](const u8* p, size_t off, size_t len) {
                                               const u32* in = reinterpret_cast<const u32*>(p);
