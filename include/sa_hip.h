@@ -283,7 +283,12 @@ int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t 
  * offsets[i+1]); row_ids[i * k .. i * k + counts[i]) = its distinct rows, ranges[i] (may be NULL) its SA range.  ONE search
  * launch finds every range and ONE more launch maps every hit of every range to its row (binary search over the row
  * table in HBM) and de-duplicates per query in LDS (k <= 4096; larger k is served per query on the host): no per-query
- * synchronisation, one copy back.  Replaces the per-query loop of suffix_array.pyx:221-247 over engine.c:1364-1388. */
+ * synchronisation, one copy back.  Replaces the per-query loop of suffix_array.pyx:221-247 over engine.c:1364-1388.
+ * In a batch of 4096 queries or more, ranges of at most 4 hits are answered by one lane each and only the longer ones by a
+ * workgroup; when Q * k row ids exceed 32 MiB the host legs go through the process's ring of pinned slabs (512 MiB, shared with
+ * the sa_hip_libsais* wrappers, given back by sa_hip_release_workspace) and the ids are widened into row_ids by worker threads.
+ * row_ids, counts and ranges are the caller's arrays (entries of row_ids beyond counts[i] are left untouched): keep them from
+ * call to call. */
 int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_t* offsets, uint64_t Q, uint32_t k,
                                   uint64_t* row_ids, uint32_t* counts, sa_hip_pair_u32* ranges);
 /* The same for a range that a batched query has already found (sa_hip_query_batch: one launch for all the ranges,
