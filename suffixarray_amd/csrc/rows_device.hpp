@@ -31,6 +31,9 @@ constexpr u32 ROWS_K_SMALL = 1536;
 constexpr u32 ROWS_SLOTS_LARGE = 16384;   // k <= 4096: 128 KB of LDS (one workgroup per CU)
 constexpr u32 ROWS_LANE_MAX = 4;          // hits of a range that one lane answers on its own (batches)
 constexpr u64 ROWS_LANE_MIN_BATCH = 4096; // smaller batches go straight to the workgroup form (one launch)
+constexpr u32 ROWS_WAVE_K_MAX = 64;       // batches, k <= 64: ranges of 5 .. ROWS_WAVE_MAX_HITS hits are walked by ONE WAVE each, 64 hits at a time
+constexpr u32 ROWS_WAVE_MAX_HITS = 4096;  //  (a table per wave never holds more than k - 1 + 64 rows: 256 slots, 8 KB per workgroup of four waves --
+constexpr u32 ROWS_WAVE_SLOTS = 256;      //   ~8000 ranges in flight on the chip instead of ~1100 workgroups, each behind the same chain of ~26 probes)
 
 struct RowsArgs {
     const u32* sa;
@@ -43,8 +46,9 @@ struct RowsArgs {
     u32 k;                           // 1 .. ROWS_K_MAX (and <= what SLOTS allows)
     u32* out_rows;                   // [q][k]
     u32* out_counts;                 // [q]
-    const u32* pending = nullptr;    // rows_kernel: the queries left for it ([*n_pending], any order), or nullptr: all q
+    const u32* pending = nullptr;    // rows_kernel / rows_wave_kernel: the queries left for it ([*n_pending], any order), or nullptr: all q
     const u32* n_pending = nullptr;
+    u32 pending_rev = 0;             // the list runs backwards from pending[q - 1] (the workgroup form's list shares the buffer with the wave form's)
 };
 
 // the row that holds text position pos: the last row whose start is <= pos (row_starts[0] = 0)
@@ -73,9 +77,11 @@ __device__ __forceinline__ u32 hits_of_range(const sa_hip_pair_u32 rg) {   // mi
 
 // One lane per query: ranges of <= ROWS_LANE_MAX hits are answered completely (distinct rows in first-hit order, at most k),
 // the others are appended to pending[] (their out_counts entry is written by rows_kernel).
-__global__ __launch_bounds__(256) void rows_lane_kernel(RowsArgs a, u32* __restrict__ pending, u32* __restrict__ n_pending) {
+// pending[0 ..) collects the ranges for the wave form (use_wave: k <= ROWS_WAVE_K_MAX and at most ROWS_WAVE_MAX_HITS hits), pending[q - 1 ..)
+// backwards those for the workgroup form; n_pending[0] / [1] their lengths.
+__global__ __launch_bounds__(256) void rows_lane_kernel(RowsArgs a, u32* __restrict__ pending, u32* __restrict__ n_pending, const int use_wave) {
     const u64 qi = (u64)blockIdx.x * 256 + threadIdx.x;
-    bool big = false;
+    bool big = false, mid = false;
     if (qi < a.q) {
         const sa_hip_pair_u32 rg = a.ranges[qi];
         const u32 count = hits_of_range(rg);
@@ -95,18 +101,78 @@ __global__ __launch_bounds__(256) void rows_lane_kernel(RowsArgs a, u32* __restr
                 }
             }
             a.out_counts[qi] = have;
+        } else if (use_wave && count <= ROWS_WAVE_MAX_HITS) {
+            mid = true;
         } else {
             big = true;
         }
     }
+    const int lane = threadIdx.x & 63;
+    const u64 mm = __ballot(mid);
+    if (mm) {
+        const int leader = __ffsll((unsigned long long)mm) - 1;
+        u32 base = 0;
+        if (lane == leader) base = atomicAdd(&n_pending[0], (u32)__popcll(mm));
+        base = __shfl(base, leader);
+        if (mid) pending[base + (u32)__popcll(mm & lanemask_lt())] = (u32)qi;
+    }
     const u64 m = __ballot(big);
     if (m) {
-        const int lane = threadIdx.x & 63;
         const int leader = __ffsll((unsigned long long)m) - 1;
         u32 base = 0;
-        if (lane == leader) base = atomicAdd(n_pending, (u32)__popcll(m));
+        if (lane == leader) base = atomicAdd(&n_pending[1], (u32)__popcll(m));
         base = __shfl(base, leader);
-        if (big) pending[base + (u32)__popcll(m & lanemask_lt())] = (u32)qi;
+        if (big) pending[a.q - 1 - (base + (u32)__popcll(m & lanemask_lt()))] = (u32)qi;
+    }
+}
+
+// LDS traffic of ONE wave ordered against itself (the waves of rows_wave_kernel run independent loops: no workgroup barrier)
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One WAVE per range of the list: the workgroup form's walk (hit -> row, first-seen test in an LDS table, new rows in hit order by a
+// ballot prefix) over 64 hits at a time with a table of the wave's own -- the same rows in the same order (a row's entry keeps the
+// smallest hit index whatever the width of the chunks that brought its hits).
+__global__ __launch_bounds__(256) void rows_wave_kernel(RowsArgs a) {
+    __shared__ unsigned long long s_tab[4][ROWS_WAVE_SLOTS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long* tab = s_tab[wave];
+    const u64 nq = (u64)*a.n_pending;
+    for (u64 w = (u64)blockIdx.x * 4 + wave; w < nq; w += (u64)gridDim.x * 4) {
+        const u64 qi = a.pending[w];
+        const sa_hip_pair_u32 rg = a.ranges[qi];
+        const u32 count = hits_of_range(rg);
+        for (u32 s = lane; s < ROWS_WAVE_SLOTS; s += 64) tab[s] = 0ull;
+        wave_lds_sync();
+        u32 have = 0;
+        for (u32 base = 0; base < count && have < a.k; base += 64) {
+            const u32 i = base + (u32)lane;
+            const bool valid = i < count;
+            u32 row = 0, slot = 0;
+            if (valid) {
+                row = row_of_pos(a, a.sa[(u64)rg.first + i]);
+                const unsigned long long key = (unsigned long long)(row + 1u) << 32;
+                slot = (row * 0x9E3779B1u) >> 24;
+                while (true) {
+                    const unsigned long long old = atomicCAS(&tab[slot], 0ull, key | i);
+                    if (old == 0ull) break;
+                    if ((old >> 32) == (key >> 32)) { atomicMin(&tab[slot], key | i); break; }
+                    slot = (slot + 1u) & (ROWS_WAVE_SLOTS - 1u);
+                }
+            }
+            wave_lds_sync();
+            const bool win = valid && (u32)tab[slot] == i;   // this hit is the first one of its row
+            const u64 m = __ballot(win);
+            if (win) {
+                const u32 p = have + (u32)__popcll(m & lanemask_lt());
+                if (p < a.k) a.out_rows[qi * a.k + p] = row;
+            }
+            have += (u32)__popcll(m);
+            wave_lds_sync();   // the reads above before the next chunk's atomics
+        }
+        if (lane == 0) a.out_counts[qi] = have < a.k ? have : a.k;
     }
 }
 
@@ -162,7 +228,7 @@ __global__ __launch_bounds__(256) void rows_kernel(RowsArgs a) {
     __shared__ u32 s_wcnt[4];
     const u64 nq = a.pending ? (u64)*a.n_pending : a.q;
     for (u64 i = blockIdx.x; i < nq; i += gridDim.x) {
-        const u64 qi = a.pending ? (u64)a.pending[i] : i;
+        const u64 qi = a.pending ? (u64)a.pending[a.pending_rev ? a.q - 1 - i : i] : i;
         rows_of_range<SLOTS>(a, qi, a.ranges[qi], s_tab, s_wcnt);
     }
 }
@@ -187,16 +253,23 @@ __global__ __launch_bounds__(256) void query_rows_one_kernel(QueryArgs qa, CodeM
     rows_of_range<SLOTS>(ra, 0, s_rg, s_tab, s_wcnt);
 }
 
-// pend: device buffer of a.q + 1 u32 (the list of the queries the lane kernel leaves + its length), or nullptr / a small
-// batch: every query goes through the workgroup form.
-inline void launch_rows(hipStream_t stream, RowsArgs a, u32* pend = nullptr) {
+// pend: device buffer of a.q + 2 u32 (the lists of the queries the lane kernel leaves + their lengths), or nullptr / a small
+// batch: every query goes through the workgroup form.  waves = false: no wave form (A/B, tests).
+inline void launch_rows(hipStream_t stream, RowsArgs a, u32* pend = nullptr, bool waves = true) {
     if (a.q == 0) return;
     if (pend && a.q >= ROWS_LANE_MIN_BATCH && a.q <= 0xFFFFFFFFull) {
         u32* n_pending = pend + a.q;
-        (void)hipMemsetAsync(n_pending, 0, 4, stream);
-        hipLaunchKernelGGL(rows_lane_kernel, dim3((u32)((a.q + 255) / 256)), dim3(256), 0, stream, a, pend, n_pending);
+        const bool use_wave = waves && a.k <= ROWS_WAVE_K_MAX;
+        (void)hipMemsetAsync(n_pending, 0, 8, stream);
+        hipLaunchKernelGGL(rows_lane_kernel, dim3((u32)((a.q + 255) / 256)), dim3(256), 0, stream, a, pend, n_pending, use_wave ? 1 : 0);
         a.pending = pend;
-        a.n_pending = n_pending;
+        if (use_wave) {
+            a.n_pending = n_pending;
+            const u64 gw = std::min<u64>((a.q + 3) / 4, 256u * 8u);
+            hipLaunchKernelGGL(rows_wave_kernel, dim3((u32)gw), dim3(256), 0, stream, a);
+        }
+        a.n_pending = n_pending + 1;
+        a.pending_rev = 1;
     }
     u64 g = a.q;
     if (a.k <= ROWS_K_SMALL) {

@@ -1102,7 +1102,9 @@ int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t 
 
 // (batches whose Q x k row ids take less than this go down by one plain copy; SA_HIP_ROWS_RING=0: always -- A/B, tests)
 static constexpr size_t ROWS_RING_MIN_BYTES = 32u << 20;
+static bool rows_waves_off() { const char* e = diag_env("SA_HIP_ROWS_WAVES"); return e && e[0] == '0'; }   // A/B, tests: no wave-per-range form
 static bool rows_lanes_off() { const char* e = diag_env("SA_HIP_ROWS_LANES"); return e && e[0] == '0'; }   // A/B, tests: every query through the workgroup form
+static bool rows_trace_on() { const char* e = diag_env("SA_HIP_ROWS_TRACE"); return e && e[0] == '1'; }   // one stderr line per large batch: where its time went
 static bool rows_ring_off() { const char* e = diag_env("SA_HIP_ROWS_RING"); return e && e[0] == '0'; }
 
 int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, const uint64_t* offsets, uint64_t Q, uint32_t k,
@@ -1152,9 +1154,14 @@ int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, co
         if (g_oneshot.ring.device == idx->device) ring = &g_oneshot.ring;
         else ring_lock.unlock();   // (the ring's copy stream lives on another device: the plain copies below)
     }
+    const bool trace = ring && rows_trace_on();
+    auto t_mark = std::chrono::steady_clock::now();
+    double t_up = 0, t_kern = 0, t_small = 0, t_rows = 0;
+    auto lap = [&](double& acc) { const auto now = std::chrono::steady_clock::now(); acc += std::chrono::duration<double, std::milli>(now - t_mark).count(); t_mark = now; };
     if (ring) {
         if ((rc = ring_upload(*ring, idx->stream, idx->device, idx->q_pat.p, patterns, (size_t)total))) return rc;
         if ((rc = ring_upload(*ring, idx->stream, idx->device, idx->q_off.p, reinterpret_cast<const u8*>(offsets), (size_t)(Q + 1) * 8))) return rc;
+        lap(t_up);
     } else {
         if (total) SA_HIP_CHECK(hipMemcpyAsync(idx->q_pat.p, patterns, total, hipMemcpyHostToDevice, idx->stream));
         SA_HIP_CHECK(hipMemcpyAsync(idx->q_off.p, offsets, (size_t)(Q + 1) * 8, hipMemcpyHostToDevice, idx->stream));
@@ -1172,18 +1179,20 @@ int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, co
             if ((rc = idx->r_rows.ensure((size_t)Q * k * 4))) return rc;
             if ((rc = idx->r_counts.ensure((size_t)Q * 4))) return rc;
             const bool lanes = Q >= ROWS_LANE_MIN_BATCH && !rows_lanes_off();
-            if (lanes && (rc = idx->r_pending.ensure(((size_t)Q + 1) * 4))) return rc;
+            if (lanes && (rc = idx->r_pending.ensure(((size_t)Q + 2) * 4))) return rc;
             RowsArgs a;
             a.sa = idx->b.sa; a.ranges = idx->q_out.as<sa_hip_pair_u32>(); a.q = Q;
             a.row_starts = idx->rows_dev.as<u64>(); a.num_rows = idx->row_starts.size(); a.k = k;
             a.coarse = (idx->rows_coarse_n > 1) ? idx->rows_coarse.as<u64>() : nullptr; a.coarse_n = idx->rows_coarse_n;
             a.out_rows = idx->r_rows.as<u32>(); a.out_counts = idx->r_counts.as<u32>();
-            launch_rows(idx->stream, a, lanes ? idx->r_pending.as<u32>() : nullptr);
+            launch_rows(idx->stream, a, lanes ? idx->r_pending.as<u32>() : nullptr, !rows_waves_off());
             SA_HIP_CHECK(hipGetLastError());
             if (ring) {
                 SA_HIP_CHECK(hipStreamSynchronize(idx->stream));
+                lap(t_kern);
                 if ((rc = ring_download<u32>(*ring, idx->device, idx->r_counts.as<u32>(), counts, (size_t)Q))) return rc;
                 if (ranges && (rc = ring_download<u32>(*ring, idx->device, idx->q_out.as<u32>(), reinterpret_cast<u32*>(ranges), (size_t)Q * 2))) return rc;
+                lap(t_small);
                 const size_t per_q = (size_t)k * 4;                                        // k <= ROWS_K_MAX: at most 16 KB
                 // whole queries per piece; about 32 pieces (1 MB .. one slab) so that a mid-size batch still spreads over all workers
                 const size_t target = std::min<size_t>(PinnedRing::SLAB_BYTES, std::max<size_t>((size_t)1 << 20, (size_t)Q * per_q / 32));
@@ -1199,6 +1208,9 @@ int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, co
                                                   for (u32 i = 0; i < c; ++i) o[i] = r[i];
                                               }
                                           });
+                lap(t_rows);
+                if (trace) fprintf(stderr, "[sa_hip rows batch] Q=%llu k=%u: patterns+offsets up %.2f ms, search+rows kernels %.2f, counts+ranges down %.2f, row ids down+widened %.2f (pieces of %zu bytes)\n",
+                                   (unsigned long long)Q, k, t_up, t_kern, t_small, t_rows, piece);
                 return rc;
             }
             std::vector<u32> rows32((size_t)Q * k);

@@ -482,12 +482,18 @@ def test_large_rows_batch_through_the_pinned_ring(gpu, monkeypatch):
         (rows3, cnt3), rg3 = idx.query_rows_batch_raw((buf, off), k)
         monkeypatch.delenv("SA_HIP_ROWS_LANES")
         assert np.array_equal(cnt0, cnt3) and np.array_equal(rg0, rg3) and np.array_equal(rows0[live], rows3[live])
+        # ... ranges of 5 .. 4096 hits by one WAVE each for k <= 64 (rows_wave_kernel): against lanes + workgroups only
+        monkeypatch.setenv("SA_HIP_ROWS_WAVES", "0")
+        (rows4, cnt4), rg4 = idx.query_rows_batch_raw((buf, off), k)
+        monkeypatch.delenv("SA_HIP_ROWS_WAVES")
+        assert np.array_equal(cnt0, cnt4) and np.array_equal(rg0, rg4) and np.array_equal(rows0[live], rows4[live])
         hits = ((rg0["second"].astype(np.int64) - rg0["first"].astype(np.int64) + 1) & 0xFFFFFFFF) * (rg0["first"] != 0xFFFFFFFF)
-        assert (hits == 0).sum() > 1000 and ((hits >= 1) & (hits <= 4)).sum() > 1000 and (hits > 4).sum() > 1000, np.bincount(np.minimum(hits, 6))
+        assert (hits == 0).sum() > 1000 and ((hits >= 1) & (hits <= 4)).sum() > 1000 and ((hits > 4) & (hits <= 4096)).sum() > 1000 \
+            and (hits > 4096).sum() > 1000, np.bincount(np.minimum(hits, 6))
         # ... and a slice of the batch against the host path (records.hpp: distinct_rows), for several k
         sl = slice(1_000_000, 1_030_000)
         sub = (buf[int(off[sl.start]):int(off[sl.stop])], (off[sl.start:sl.stop + 1] - off[sl.start]).astype(np.uint64))
-        for kk in (1, 2, 3, 13, 40):
+        for kk in (1, 2, 3, 13, 40, 64, 65, 100):
             monkeypatch.setenv("SA_HIP_HOST_ROWS", "1")
             (hr, hc), hrg = idx.query_rows_batch_raw(sub, kk)
             monkeypatch.delenv("SA_HIP_HOST_ROWS")

@@ -1,5 +1,5 @@
 """The names batch all the way to row ids (bench.py: secondary.config5_csv_50M_rows.names_batch_1e6.rows_batch) on its own, A/B of
-the forms of the rows kernels (csrc/rows_device.hpp) and of the host legs by SA_HIP_ROWS_LANES / SA_HIP_ROWS_RING, every variant's rows
+the forms of the rows kernels (csrc/rows_device.hpp) and of the host legs by SA_HIP_ROWS_LANES / SA_HIP_ROWS_WAVES / SA_HIP_ROWS_RING, every variant's rows
 against the first (profiles/r04_o_names_rows.log also has the 1024-slot table that was measured and not kept):
     python3 tools/gpu_names_rows.py [rows] [queries] [k]"""
 import os
@@ -36,8 +36,8 @@ with _capi.DeviceIndex(col.size, 0) as idx:
     idx.set_rows(starts)
     idx.deep_keys(2)
     first = None
-    for name, env in (("lanes (default)", {}), ("SA_HIP_ROWS_LANES=0", {"SA_HIP_ROWS_LANES": "0"}), ("SA_HIP_ROWS_RING=0", {"SA_HIP_ROWS_RING": "0"}),
-                      ("lanes again", {})):
+    for name, env in (("lanes + waves (default)", {}), ("SA_HIP_ROWS_WAVES=0", {"SA_HIP_ROWS_WAVES": "0"}), ("SA_HIP_ROWS_LANES=0", {"SA_HIP_ROWS_LANES": "0"}),
+                      ("SA_HIP_ROWS_RING=0", {"SA_HIP_ROWS_RING": "0"}), ("lanes + waves again", {})):
         for k_, v_ in env.items():
             os.environ[k_] = v_
         out = (np.empty((a.size, K), dtype=np.uint64), np.zeros(a.size, dtype=np.uint32), np.zeros(a.size, dtype=_capi.PAIR_DTYPE))
