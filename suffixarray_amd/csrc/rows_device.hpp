@@ -31,9 +31,11 @@ constexpr u32 ROWS_K_SMALL = 1536;
 constexpr u32 ROWS_SLOTS_LARGE = 16384;   // k <= 4096: 128 KB of LDS (one workgroup per CU)
 constexpr u32 ROWS_LANE_MAX = 4;          // hits of a range that one lane answers on its own (batches)
 constexpr u64 ROWS_LANE_MIN_BATCH = 4096; // smaller batches go straight to the workgroup form (one launch)
-constexpr u32 ROWS_WAVE_K_MAX = 64;       // batches, k <= 64: ranges of 5 .. ROWS_WAVE_MAX_HITS hits are walked by ONE WAVE each, 64 hits at a time
+constexpr u32 ROWS_WAVE_K_MAX = 64;       // batches, k <= 64: ranges of more than ROWS_LANE_MAX hits are walked by ONE WAVE each, 64 hits at a time
 constexpr u32 ROWS_WAVE_MAX_HITS = 4096;  //  (a table per wave never holds more than k - 1 + 64 rows: 256 slots, 8 KB per workgroup of four waves --
-constexpr u32 ROWS_WAVE_SLOTS = 256;      //   ~8000 ranges in flight on the chip instead of ~1100 workgroups, each behind the same chain of ~26 probes)
+constexpr u32 ROWS_WAVE_SLOTS = 256;      //   ~8000 ranges in flight on the chip instead of ~1100 workgroups, each behind the same chain of ~26 probes);
+                                          //  a range whose first ROWS_WAVE_MAX_HITS hits do not yield k rows (many hits in few rows) is handed on to the
+                                          //  workgroup form, which walks 256 hits at a time and starts it again
 
 struct RowsArgs {
     const u32* sa;
@@ -48,7 +50,8 @@ struct RowsArgs {
     u32* out_counts;                 // [q]
     const u32* pending = nullptr;    // rows_kernel / rows_wave_kernel: the queries left for it ([*n_pending], any order), or nullptr: all q
     const u32* n_pending = nullptr;
-    u32 pending_rev = 0;             // the list runs backwards from pending[q - 1] (the workgroup form's list shares the buffer with the wave form's)
+    u32* handoff = nullptr;          // rows_wave_kernel: the workgroup form's list and its length, for the ranges it gives up
+    u32* n_handoff = nullptr;
 };
 
 // the row that holds text position pos: the last row whose start is <= pos (row_starts[0] = 0)
@@ -77,8 +80,8 @@ __device__ __forceinline__ u32 hits_of_range(const sa_hip_pair_u32 rg) {   // mi
 
 // One lane per query: ranges of <= ROWS_LANE_MAX hits are answered completely (distinct rows in first-hit order, at most k),
 // the others are appended to pending[] (their out_counts entry is written by rows_kernel).
-// pending[0 ..) collects the ranges for the wave form (use_wave: k <= ROWS_WAVE_K_MAX and at most ROWS_WAVE_MAX_HITS hits), pending[q - 1 ..)
-// backwards those for the workgroup form; n_pending[0] / [1] their lengths.
+// pending[0 .. q) collects the ranges for the wave form (use_wave: k <= ROWS_WAVE_K_MAX), pending[q .. 2q) those for the workgroup form
+// (without the wave form: all the others); n_pending[0] / [1] their lengths.
 __global__ __launch_bounds__(256) void rows_lane_kernel(RowsArgs a, u32* __restrict__ pending, u32* __restrict__ n_pending, const int use_wave) {
     const u64 qi = (u64)blockIdx.x * 256 + threadIdx.x;
     bool big = false, mid = false;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void rows_lane_kernel(RowsArgs a, u32* __restr
                 }
             }
             a.out_counts[qi] = have;
-        } else if (use_wave && count <= ROWS_WAVE_MAX_HITS) {
+        } else if (use_wave) {
             mid = true;
         } else {
             big = true;
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void rows_lane_kernel(RowsArgs a, u32* __restr
         u32 base = 0;
         if (lane == leader) base = atomicAdd(&n_pending[1], (u32)__popcll(m));
         base = __shfl(base, leader);
-        if (big) pending[a.q - 1 - (base + (u32)__popcll(m & lanemask_lt()))] = (u32)qi;
+        if (big) pending[a.q + base + (u32)__popcll(m & lanemask_lt())] = (u32)qi;
     }
 }
 
@@ -147,7 +150,8 @@ __global__ __launch_bounds__(256) void rows_wave_kernel(RowsArgs a) {
         for (u32 s = lane; s < ROWS_WAVE_SLOTS; s += 64) tab[s] = 0ull;
         wave_lds_sync();
         u32 have = 0;
-        for (u32 base = 0; base < count && have < a.k; base += 64) {
+        const u32 walk = count < ROWS_WAVE_MAX_HITS ? count : ROWS_WAVE_MAX_HITS;
+        for (u32 base = 0; base < walk && have < a.k; base += 64) {
             const u32 i = base + (u32)lane;
             const bool valid = i < count;
             u32 row = 0, slot = 0;
@@ -172,7 +176,11 @@ __global__ __launch_bounds__(256) void rows_wave_kernel(RowsArgs a) {
             have += (u32)__popcll(m);
             wave_lds_sync();   // the reads above before the next chunk's atomics
         }
-        if (lane == 0) a.out_counts[qi] = have < a.k ? have : a.k;
+        if (have < a.k && walk < count) {       // (uniform) handed on: the workgroup form writes this range's rows and count
+            if (lane == 0) a.handoff[atomicAdd(a.n_handoff, 1u)] = (u32)qi;
+        } else if (lane == 0) {
+            a.out_counts[qi] = have < a.k ? have : a.k;
+        }
     }
 }
 
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(256) void rows_kernel(RowsArgs a) {
     __shared__ u32 s_wcnt[4];
     const u64 nq = a.pending ? (u64)*a.n_pending : a.q;
     for (u64 i = blockIdx.x; i < nq; i += gridDim.x) {
-        const u64 qi = a.pending ? (u64)a.pending[a.pending_rev ? a.q - 1 - i : i] : i;
+        const u64 qi = a.pending ? (u64)a.pending[i] : i;
         rows_of_range<SLOTS>(a, qi, a.ranges[qi], s_tab, s_wcnt);
     }
 }
@@ -253,23 +261,25 @@ __global__ __launch_bounds__(256) void query_rows_one_kernel(QueryArgs qa, CodeM
     rows_of_range<SLOTS>(ra, 0, s_rg, s_tab, s_wcnt);
 }
 
-// pend: device buffer of a.q + 2 u32 (the lists of the queries the lane kernel leaves + their lengths), or nullptr / a small
+// pend: device buffer of 2 * a.q + 2 u32 (the two lists of the queries the lane kernel leaves + their lengths), or nullptr / a small
 // batch: every query goes through the workgroup form.  waves = false: no wave form (A/B, tests).
 inline void launch_rows(hipStream_t stream, RowsArgs a, u32* pend = nullptr, bool waves = true) {
     if (a.q == 0) return;
     if (pend && a.q >= ROWS_LANE_MIN_BATCH && a.q <= 0xFFFFFFFFull) {
-        u32* n_pending = pend + a.q;
+        u32* n_pending = pend + 2 * a.q;
         const bool use_wave = waves && a.k <= ROWS_WAVE_K_MAX;
         (void)hipMemsetAsync(n_pending, 0, 8, stream);
         hipLaunchKernelGGL(rows_lane_kernel, dim3((u32)((a.q + 255) / 256)), dim3(256), 0, stream, a, pend, n_pending, use_wave ? 1 : 0);
-        a.pending = pend;
         if (use_wave) {
+            a.pending = pend;
             a.n_pending = n_pending;
+            a.handoff = pend + a.q;
+            a.n_handoff = n_pending + 1;
             const u64 gw = std::min<u64>((a.q + 3) / 4, 256u * 8u);
             hipLaunchKernelGGL(rows_wave_kernel, dim3((u32)gw), dim3(256), 0, stream, a);
         }
+        a.pending = pend + a.q;
         a.n_pending = n_pending + 1;
-        a.pending_rev = 1;
     }
     u64 g = a.q;
     if (a.k <= ROWS_K_SMALL) {

@@ -1179,7 +1179,7 @@ int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, co
             if ((rc = idx->r_rows.ensure((size_t)Q * k * 4))) return rc;
             if ((rc = idx->r_counts.ensure((size_t)Q * 4))) return rc;
             const bool lanes = Q >= ROWS_LANE_MIN_BATCH && !rows_lanes_off();
-            if (lanes && (rc = idx->r_pending.ensure(((size_t)Q + 2) * 4))) return rc;
+            if (lanes && (rc = idx->r_pending.ensure((2 * (size_t)Q + 2) * 4))) return rc;
             RowsArgs a;
             a.sa = idx->b.sa; a.ranges = idx->q_out.as<sa_hip_pair_u32>(); a.q = Q;
             a.row_starts = idx->rows_dev.as<u64>(); a.num_rows = idx->row_starts.size(); a.k = k;

@@ -509,6 +509,34 @@ def test_large_rows_batch_through_the_pinned_ring(gpu, monkeypatch):
             assert (int(rg[0]), int(rg[1])) == (int(rg1[q]["first"]), int(rg1[q]["second"])), (q, p)
 
 
+def test_rows_batch_wave_form_hands_long_ranges_on(gpu, monkeypatch):
+    """Many hits in few rows: a range whose first 4096 hits do not yield k distinct rows is given up by the wave form and
+    walked again by the workgroup form (rows_device.hpp: handoff list) -- three long rows of one letter, a batch large enough
+    for the lane / wave forms, against the host path and against the batch without the wave form."""
+    row = b"a" * 20_000 + b"b" * 50 + b"\n"
+    text = np.frombuffer(row * 3 + b"abab\nba\n", np.uint8)
+    starts = np.array([0, len(row), 2 * len(row), 3 * len(row), 3 * len(row) + 5], dtype=np.uint64)
+    base = [b"a", b"aa", b"aaaaaaaa", b"b", b"bb", b"ab", b"ba", b"a" * 40, b"zz", b"abab", b"\n", b"b\n", b"a" * 19_999, b"ab" * 2]
+    pats = [base[i % len(base)] for i in range(5000)]
+    with gpu.DeviceIndex(text.size, 0) as idx:
+        idx.build(text)
+        idx.set_rows(starts)
+        for k in (1, 3, 4, 13, 64):
+            monkeypatch.setenv("SA_HIP_HOST_ROWS", "1")
+            host_rows, host_rg = idx.query_rows_batch(pats[:len(base)], k)
+            monkeypatch.delenv("SA_HIP_HOST_ROWS")
+            dev_rows, dev_rg = idx.query_rows_batch(pats, k)
+            monkeypatch.setenv("SA_HIP_ROWS_WAVES", "0")
+            nw_rows, nw_rg = idx.query_rows_batch(pats, k)
+            monkeypatch.delenv("SA_HIP_ROWS_WAVES")
+            assert np.array_equal(dev_rg, nw_rg) and np.array_equal(dev_rg[:len(base)], host_rg)
+            for i, (a, b) in enumerate(zip(dev_rows, nw_rows)):
+                assert np.array_equal(a, b), (k, pats[i], a, b)
+                assert np.array_equal(a, host_rows[i % len(base)]), (k, pats[i], a, host_rows[i % len(base)])
+        rows, _ = idx.query_rows_batch(pats[:len(base)] * 400, 13)
+        assert sorted(rows[0].tolist()) == [0, 1, 2, 3, 4] and sorted(rows[3].tolist()) == [0, 1, 2, 3, 4] and rows[8].size == 0
+
+
 def test_api_edge_cases(gpu):
     lib = gpu.lib()
     import ctypes as C
