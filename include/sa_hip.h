@@ -284,8 +284,8 @@ int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t 
  * launch finds every range and ONE more launch maps every hit of every range to its row (binary search over the row
  * table in HBM) and de-duplicates per query in LDS (k <= 4096; larger k is served per query on the host): no per-query
  * synchronisation, one copy back.  Replaces the per-query loop of suffix_array.pyx:221-247 over engine.c:1364-1388.
- * In a batch of 4096 queries or more, ranges of at most 4 hits are answered by one lane each and only the longer ones by a
- * workgroup; when Q * k row ids exceed 32 MiB the host legs go through the process's ring of pinned slabs (512 MiB, shared with
+ * In a batch of 4096 queries or more, ranges of at most 4 hits are answered by one lane each, longer ones by one wave each
+ * (k <= 64) or one workgroup each; when Q * k row ids exceed 32 MiB the host legs go through the process's ring of pinned slabs (512 MiB, shared with
  * the sa_hip_libsais* wrappers, given back by sa_hip_release_workspace) and the ids are widened into row_ids by worker threads.
  * row_ids, counts and ranges are the caller's arrays (entries of row_ids beyond counts[i] are left untouched): keep them from
  * call to call. */
