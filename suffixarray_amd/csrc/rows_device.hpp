@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void query_rows_one_kernel(QueryArgs qa, CodeM
 
 // pend: device buffer of 2 * a.q + 2 u32 (the two lists of the queries the lane kernel leaves + their lengths), or nullptr / a small
 // batch: every query goes through the workgroup form.  waves = false: no wave form (A/B, tests).
-inline void launch_rows(hipStream_t stream, RowsArgs a, u32* pend = nullptr, bool waves = true) {
+inline void launch_rows(hipStream_t stream, RowsArgs a, u32* pend = nullptr, bool waves = true, u32 wave_groups_per_cu = 8) {
     if (a.q == 0) return;
     if (pend && a.q >= ROWS_LANE_MIN_BATCH && a.q <= 0xFFFFFFFFull) {
         u32* n_pending = pend + 2 * a.q;
@@ -277,7 +277,7 @@ inline void launch_rows(hipStream_t stream, RowsArgs a, u32* pend = nullptr, boo
             a.n_pending = n_pending;
             a.handoff = pend + a.q;
             a.n_handoff = n_pending + 1;
-            const u64 gw = std::min<u64>((a.q + 3) / 4, 256u * 8u);
+            const u64 gw = std::min<u64>((a.q + 3) / 4, 256u * (u64)wave_groups_per_cu);
             hipLaunchKernelGGL(rows_wave_kernel, dim3((u32)gw), dim3(256), 0, stream, a);
         }
         a.pending = pend + a.q;

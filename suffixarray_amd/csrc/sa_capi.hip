@@ -1103,6 +1103,7 @@ int sa_hip_index_query_rows(sa_hip_index* idx, const uint8_t* pattern, uint64_t 
 // (batches whose Q x k row ids take less than this go down by one plain copy; SA_HIP_ROWS_RING=0: always -- A/B, tests)
 static constexpr size_t ROWS_RING_MIN_BYTES = 32u << 20;
 static bool rows_waves_off() { const char* e = diag_env("SA_HIP_ROWS_WAVES"); return e && e[0] == '0'; }   // A/B, tests: no wave-per-range form
+static u32 rows_wave_groups() { const char* e = diag_env("SA_HIP_ROWS_WAVE_GROUPS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 256 ? (u32)v : 8u; }   // A/B: workgroups of the wave form per CU
 static bool rows_lanes_off() { const char* e = diag_env("SA_HIP_ROWS_LANES"); return e && e[0] == '0'; }   // A/B, tests: every query through the workgroup form
 static bool rows_trace_on() { const char* e = diag_env("SA_HIP_ROWS_TRACE"); return e && e[0] == '1'; }   // one stderr line per large batch: where its time went
 static bool rows_ring_off() { const char* e = diag_env("SA_HIP_ROWS_RING"); return e && e[0] == '0'; }
@@ -1185,7 +1186,7 @@ int sa_hip_index_query_rows_batch(sa_hip_index* idx, const uint8_t* patterns, co
             a.row_starts = idx->rows_dev.as<u64>(); a.num_rows = idx->row_starts.size(); a.k = k;
             a.coarse = (idx->rows_coarse_n > 1) ? idx->rows_coarse.as<u64>() : nullptr; a.coarse_n = idx->rows_coarse_n;
             a.out_rows = idx->r_rows.as<u32>(); a.out_counts = idx->r_counts.as<u32>();
-            launch_rows(idx->stream, a, lanes ? idx->r_pending.as<u32>() : nullptr, !rows_waves_off());
+            launch_rows(idx->stream, a, lanes ? idx->r_pending.as<u32>() : nullptr, !rows_waves_off(), rows_wave_groups());
             SA_HIP_CHECK(hipGetLastError());
             if (ring) {
                 SA_HIP_CHECK(hipStreamSynchronize(idx->stream));

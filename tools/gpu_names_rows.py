@@ -37,7 +37,7 @@ with _capi.DeviceIndex(col.size, 0) as idx:
     idx.deep_keys(2)
     first = None
     for name, env in (("lanes + waves (default)", {}), ("SA_HIP_ROWS_WAVES=0", {"SA_HIP_ROWS_WAVES": "0"}), ("SA_HIP_ROWS_LANES=0", {"SA_HIP_ROWS_LANES": "0"}),
-                      ("SA_HIP_ROWS_RING=0", {"SA_HIP_ROWS_RING": "0"}), ("lanes + waves again", {})):
+                      ("SA_HIP_ROWS_RING=0", {"SA_HIP_ROWS_RING": "0"}), ("wave groups 4", {"SA_HIP_ROWS_WAVE_GROUPS": "4"}), ("wave groups 16", {"SA_HIP_ROWS_WAVE_GROUPS": "16"}), ("wave groups 32", {"SA_HIP_ROWS_WAVE_GROUPS": "32"}), ("wave groups 64", {"SA_HIP_ROWS_WAVE_GROUPS": "64"}), ("lanes + waves again", {})):
         for k_, v_ in env.items():
             os.environ[k_] = v_
         out = (np.empty((a.size, K), dtype=np.uint64), np.zeros(a.size, dtype=np.uint32), np.zeros(a.size, dtype=_capi.PAIR_DTYPE))
